@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE'S OWN CODE (imported from /root/reference) and the
+container's transformers copy on the seeded synthetic checkpoint (meshanything_amd/checkpoint.py).
+
+Runs only in the authoring container (needs /root/reference); the fixtures it writes are committed and
+travel to the GPU box.  Nothing here is imported by the product.  Recipe: SURVEY.md Appendix B --
+stub the import-time-only modules that are not installed (omegaconf, trimesh, skimage, cv2, mesh2sdf),
+patch `to_bettertransformer` to the identity (vanilla BertLayer = same math) and make
+`AutoConfig.from_pretrained("bert-base-uncased")` return `BertConfig()` (its defaults are bert-base).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from meshanything_amd.config import MAConfig            # noqa: E402
+from meshanything_amd.checkpoint import synthetic_state_dict, PE, SM, DEC, TOK  # noqa: E402
+
+
+def _stub_modules():
+    for name in ("omegaconf", "trimesh", "skimage", "skimage.measure", "cv2", "mesh2sdf", "mesh2sdf.core"):
+        try:
+            __import__(name)
+        except Exception:
+            m = types.ModuleType(name)
+            if name == "omegaconf":
+                m.OmegaConf = type("OmegaConf", (), {})
+                m.DictConfig = dict
+            sys.modules[name] = m
+    import transformers
+    transformers.PreTrainedModel.to_bettertransformer = lambda self: self
+    _orig = transformers.AutoConfig.from_pretrained
+
+    def _from_pretrained(name, *a, **k):
+        if name == "bert-base-uncased":
+            return transformers.BertConfig()
+        return _orig(name, *a, **k)
+    transformers.AutoConfig.from_pretrained = staticmethod(_from_pretrained)
+
+
+def build_perceiver(cfg: MAConfig, sd):
+    from MeshAnything.miche.michelangelo.models.tsal.sal_perceiver import AlignedShapeLatentPerceiver
+    from MeshAnything.miche.michelangelo.models.tsal.clip_asl_module import CLIPAlignedShapeAsLatentModule
+    shape_model = AlignedShapeLatentPerceiver(
+        device=None, dtype=None, num_latents=cfg.num_latents, embed_dim=cfg.embed_dim, point_feats=3,
+        num_freqs=cfg.num_freqs, include_pi=False, heads=cfg.enc_heads, width=cfg.enc_width,
+        num_encoder_layers=cfg.enc_layers, num_decoder_layers=cfg.shape_layers, use_ln_post=True,
+        init_scale=0.25, qkv_bias=False, use_checkpoint=True)
+    model = CLIPAlignedShapeAsLatentModule(shape_model=shape_model)
+    sub = {k[len(PE):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(PE)}
+    missing, unexpected = model.load_state_dict(sub, strict=True), None
+    return model.eval()
+
+
+class RefPointEncoder:
+    """The 12 lines of AlignedShapeAsLatentPLModule.encode_latents / to_shape_latents (asl_pl_module.py:145-157,
+    182-185) driven on the reference's own perceiver (the PL module itself needs omegaconf/pytorch_lightning)."""
+    def __init__(self, model):
+        self.model = model
+
+    @torch.no_grad()
+    def encode_latents(self, surface):
+        pc = surface[..., 0:3]
+        feats = surface[..., 3:6]
+        shape_embed, shape_latents = self.model.shape_model.encode_latents(pc=pc, feats=feats)
+        shape_embed = shape_embed.unsqueeze(1)
+        return torch.cat([shape_embed, shape_latents], dim=1)
+
+    @torch.no_grad()
+    def to_shape_latents(self, latents):
+        shape_zq, posterior = self.model.shape_model.encode_kl_embed(latents, sample_posterior=False)
+        return self.model.shape_model.decode(shape_zq)
+
+
+def synth_cloud(seed: int, n: int) -> np.ndarray:
+    """SURVEY.md section 8d cfg 3: unit-sphere directions * U(0.3,1) radius, normals = directions (pre-normalisation)."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(n, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    r = 0.3 + 0.7 * torch.rand(n, 1, generator=g)
+    return torch.cat([d * r, d], dim=-1).numpy().astype(np.float32)
+
+
+def golden_dataset(out):
+    import main as ref_main                                            # /root/reference/main.py
+    src = np.load(os.path.join(REF, "pc_examples/mouse.npy"))
+    np.random.seed(0)                                                  # accelerate.set_seed(0) -> np.random.seed(0)
+    ds = ref_main.Dataset("pc_normal", [os.path.join(REF, "pc_examples/mouse.npy")])
+    item = ds[0]["pc_normal"]
+    out["mouse_raw"] = src
+    out["mouse_norm"] = item
+    out["mouse_norm_sha256"] = np.frombuffer(hashlib.sha256(item.tobytes()).digest(), dtype=np.uint8)
+    # a float32 cloud through the same normalisation
+    cloud = synth_cloud(7, 5000)
+    np.random.seed(3)
+    idx = np.random.choice(cloud.shape[0], 4096, replace=False)
+    ds.data = [{"pc_normal": cloud[idx], "uid": "synth"}]
+    out["synth_raw"] = cloud
+    out["synth_norm"] = ds[0]["pc_normal"]
+    print("dataset: mouse sha256", hashlib.sha256(item.tobytes()).hexdigest())
+
+
+def golden_encoder(out, cfg: MAConfig, sd, tag: str, pc_normal: np.ndarray, rows):
+    from MeshAnything.models.meshanything import MeshAnything as RefMeshAnything
+    enc = RefPointEncoder(build_perceiver(cfg, sd))
+    x = torch.from_numpy(pc_normal.astype(np.float32))[None]
+    lat = enc.encode_latents(x)
+    shp = enc.to_shape_latents(lat[:, 1:])
+    ns = types.SimpleNamespace()
+    ns.cond_length = cfg.cond_length
+    ns.config = types.SimpleNamespace(word_embed_proj_dim=cfg.hidden)
+    ns.cond_head_proj = torch.nn.Linear(cfg.enc_width, cfg.hidden)
+    ns.cond_proj = torch.nn.Linear(2 * cfg.enc_width, cfg.hidden)
+    ns.cond_head_proj.load_state_dict({"weight": torch.from_numpy(sd["cond_head_proj.weight"]), "bias": torch.from_numpy(sd["cond_head_proj.bias"])})
+    ns.cond_proj.load_state_dict({"weight": torch.from_numpy(sd["cond_proj.weight"]), "bias": torch.from_numpy(sd["cond_proj.bias"])})
+    ns.point_encoder = enc
+    with torch.no_grad():
+        prefix = RefMeshAnything.process_point_feature(ns, lat)          # meshanything.py:125-132, unbound
+    from MeshAnything.miche.michelangelo.models.modules.embedder import FourierEmbedder
+    four = FourierEmbedder(num_freqs=cfg.num_freqs, include_pi=False)(x[0, :16, :3])
+    out[f"{tag}_input"] = pc_normal
+    out[f"{tag}_fourier16"] = four.numpy()
+    rows = np.asarray(rows)
+    out[f"{tag}_rows"] = rows
+    out[f"{tag}_latents_rows"] = lat[0, rows].numpy()
+    out[f"{tag}_latents_cols8"] = lat[0, :, :8].numpy()
+    out[f"{tag}_shape_rows"] = shp[0, rows[rows < cfg.num_latents]].numpy()
+    out[f"{tag}_shape_cols8"] = shp[0, :, :8].numpy()
+    out[f"{tag}_prefix_rows"] = prefix[0, rows].numpy()
+    out[f"{tag}_prefix_cols8"] = prefix[0, :, :8].numpy()
+    out[f"{tag}_stats"] = np.array([lat.double().sum(), lat.double().abs().sum(), shp.double().sum(), shp.double().abs().sum(),
+                                    prefix.double().sum(), prefix.double().abs().sum()])
+    print(f"encoder[{tag}]: latents absmax {lat.abs().max():.3f} shape absmax {shp.abs().max():.3f} prefix absmax {prefix.abs().max():.3f}")
+    return lat, prefix
+
+
+def golden_decoder_embed(out, cfg: MAConfig, sd):
+    """embed_with_vae (shape_opt.py:237-245), OPTFacePositionalEmbedding (448-460), cond_embed (326-328),
+    OPTLearnedPositionalEmbedding ([3p], container copy) driven exactly as ShapeOPTDecoder.forward 318-364 does."""
+    from MeshAnything.models.shape_opt import ShapeOPTConfig, ShapeOPTDecoder
+    c = ShapeOPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=1, ffn_dim=cfg.ffn,
+                       num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                       do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu",
+                       bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    c.quantize_codebook_dim = cfg.codebook_dim
+    c.face_per_token = 9
+    c.cond_length = cfg.cond_length
+    dec = ShapeOPTDecoder(c).eval()
+    for nm in ("extra_embeds.weight", "input_layer.weight", "input_layer.bias", "embed_positions.weight",
+               "token_embed_positions.weight", "cond_embed.weight"):
+        obj = dec
+        parts = nm.split(".")
+        for p_ in parts[:-1]:
+            obj = getattr(obj, p_)
+        getattr(obj, parts[-1]).data.copy_(torch.from_numpy(sd[DEC + nm]))
+    dec.quantize_codebooks = torch.nn.Parameter(torch.from_numpy(sd[DEC + "quantize_codebooks"]))
+    T = cfg.cond_length
+    ts = [1, 2, 3, 4, 10, 11, 12, 20, cfg.max_new_tokens - 1]
+    toks = [0, 5, 3, cfg.vocab - 1, 7, 2, 9, 1, 33]
+    es = []
+    with torch.no_grad():
+        for t, tok in zip(ts, toks):
+            input_ids = torch.tensor([[tok]])
+            attention_mask = torch.ones(1, T + t, dtype=torch.long)      # generate(): prefix + t generated so far
+            e = dec.embed_with_vae(input_ids)
+            e = e + dec.token_embed_positions(attention_mask[:, dec.cond_length:], None, input_ids, dec.face_per_token)
+            e = e + dec.cond_embed(torch.ones(1, 1).long())
+            pos = dec.embed_positions(attention_mask, T + t - 1)
+            es.append((e + pos)[0, 0].numpy())
+        # prefill: inputs_embeds + cond_embed[0] + positions
+        pre = torch.from_numpy(np.arange(T * cfg.hidden, dtype=np.float32).reshape(1, T, cfg.hidden) * 1e-3)
+        h0 = pre + dec.cond_embed(torch.zeros(1, T).long()) + dec.embed_positions(torch.ones(1, T, dtype=torch.long), 0)
+    out["dec_embed_t"] = np.array(ts)
+    out["dec_embed_tok"] = np.array(toks)
+    out["dec_embed_e"] = np.stack(es)
+    out["dec_prefill_h0_rows"] = h0[0, [0, 1, T - 1]].numpy()
+    print("decoder embed: done")
+
+
+def golden_opt_layers(out, cfg: MAConfig, sd):
+    """[3p] OPTDecoderLayer (post-LN) x cfg.layers, causal, eager attention -- the container's transformers copy."""
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+    c = OPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                  num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                  do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu")
+    c._attn_implementation = "eager"
+    layers = [OPTDecoderLayer(c, layer_idx=i).eval() for i in range(cfg.layers)]
+    for i, L in enumerate(layers):
+        sub = {k[len(DEC + f"layers.{i}."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(DEC + f"layers.{i}.")}
+        L.load_state_dict(sub, strict=True)
+    S = cfg.cond_length + 6
+    g = torch.Generator().manual_seed(11)
+    h = torch.randn(1, S, cfg.hidden, generator=g)
+    mask = torch.full((S, S), float("-inf")).triu(1)[None, None]
+    x = h
+    with torch.no_grad():
+        for L in layers:
+            x = L(x, attention_mask=mask)
+            if isinstance(x, tuple):
+                x = x[0]
+    out["opt_h_in"] = h.numpy()
+    out["opt_h_out"] = x.numpy()
+    print("opt layers: out absmax", float(x.abs().max()))
+
+
+def golden_detok(out, cfg: MAConfig, sd, tag: str, lat: torch.Tensor, seed: int):
+    from MeshAnything.models.meshanything import NoiseResistantDecoder, MeshAnything as RefMeshAnything, undiscretize
+    import transformers
+    if cfg.tok_width != 768:
+        _orig = transformers.AutoConfig.from_pretrained
+
+        def _fp(name, *a, **k):
+            return transformers.BertConfig(hidden_size=cfg.tok_width, num_attention_heads=cfg.tok_heads,
+                                           intermediate_size=cfg.tok_ffn)
+        transformers.AutoConfig.from_pretrained = staticmethod(_fp)
+    args = types.SimpleNamespace(codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim)
+    tok = NoiseResistantDecoder(args)
+    if cfg.tok_width != 768:
+        transformers.AutoConfig.from_pretrained = staticmethod(_orig)
+        # the reference hard-codes these (meshanything.py:27,31-35); rebuild them at the test shape
+        tok.pos_embedding = torch.nn.Embedding(cfg.tok_max_pos, cfg.tok_width)
+        tok.cond_length = cfg.cond_length
+        tok.cond_dim = cfg.enc_width
+        tok.point_pe = torch.nn.Embedding(cfg.cond_length, cfg.tok_width)
+        tok.cond_proj = torch.nn.Linear(cfg.enc_width, cfg.tok_width)
+        tok.cond_head_proj = torch.nn.Linear(cfg.enc_width, cfg.tok_width)
+    assert len(tok.decoder.layer) == 6
+    tok.decoder.layer = tok.decoder.layer[:cfg.tok_layers]
+    sub = {k[len(TOK):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(TOK)}
+    tok.load_state_dict(sub, strict=True)
+    tok.eval()
+    rng = np.random.default_rng(seed)
+    nf = cfg.n_max_faces
+    ids = rng.integers(0, cfg.codebook_size, size=(1, nf * 9)).astype(np.int64)
+    n_valid = max(2, nf * 2 // 3)
+    ids[0, n_valid * 9:] = -1                     # tail faces padded (stream ended)
+    ids[0, 9 * 1 + 4] = -1                        # a special token mid-sequence kills just that face
+    ids_t = torch.from_numpy(ids)
+    ns = types.SimpleNamespace(num_quantizers=3)
+    ns.transformer = types.SimpleNamespace(model=types.SimpleNamespace(decoder=types.SimpleNamespace(
+        quantize_codebooks=torch.from_numpy(sd[DEC + "quantize_codebooks"]))))
+    with torch.no_grad():
+        codes = RefMeshAnything.get_codes(ns, ids_t)                  # meshanything.py:178-212, unbound
+        coords = tok(ids_t, codes, point_feature=lat)                 # meshanything.py:50-80
+        # logits for margin information (same modules, same order as forward 50-69)
+        pf = tok.process_point_feature(lat)
+    out[f"{tag}_detok_ids"] = ids
+    out[f"{tag}_detok_codes_rows"] = codes[0, [0, 1, 5, 3 * n_valid - 1, 3 * nf - 1]].numpy()
+    out[f"{tag}_detok_codes_stats"] = np.array([codes.double().sum(), codes.double().abs().sum()])
+    out[f"{tag}_detok_coords"] = coords.numpy()
+    out[f"{tag}_detok_pf_rows"] = pf[0, [0, 1, cfg.cond_length - 1]].numpy()
+    out["undiscretize"] = undiscretize(torch.arange(128), low=-0.5, high=0.5, num_discrete=128).numpy()
+    print(f"detok[{tag}]: valid faces", int((~torch.isnan(coords[0, :, 0, 0])).sum()), "of", nf)
+
+
+def golden_warpers(out):
+    """[3p] TopKLogitsWarper(50) -> TopPLogitsWarper(0.95) -> softmax, the chain `generate(do_sample=True, top_k=50,
+    top_p=0.95)` builds (meshanything.py:153-162)."""
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(5)
+    rows = []
+    for V, scale in ((8195, 1.0), (8195, 4.0), (64, 1.0), (64, 0.05), (8195, 0.2)):
+        logits = torch.randn(1, V, generator=g) * scale
+        s = TopKLogitsWarper(top_k=50)(None, logits.clone())
+        s = TopPLogitsWarper(top_p=0.95)(None, s)
+        probs = torch.softmax(s, dim=-1)[0]
+        rows.append((logits[0].numpy(), probs.numpy()))
+    for i, (lg, pr) in enumerate(rows):
+        out[f"warp_logits_{i}"] = lg
+        out[f"warp_probs_{i}"] = pr
+    out["warp_n"] = np.array([len(rows)])
+    print("warpers: kept counts", [int((pr > 0).sum()) for _, pr in rows])
+
+
+def main():
+    _stub_modules()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    g = {}
+    golden_dataset(g)
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **g)
+
+    tiny = MAConfig.tiny()
+    sd_t = synthetic_state_dict(tiny, include_unused=True)
+    g = {}
+    cloud = synth_cloud(1, tiny.n_points)
+    from oracle.meshanything_oracle import normalize_pc
+    pc_t = normalize_pc(cloud)
+    lat_t, _ = golden_encoder(g, tiny, sd_t, "tiny", pc_t, rows=list(range(tiny.cond_length)))
+    golden_decoder_embed(g, tiny, sd_t)
+    golden_opt_layers(g, tiny, sd_t)
+    golden_detok(g, tiny, sd_t, "tiny", lat_t, seed=21)
+    golden_warpers(g)
+    np.savez_compressed(os.path.join(HERE, "tiny.npz"), **g)
+
+    full = MAConfig.full()
+    sd_f = synthetic_state_dict(full, include_unused=True)
+    g = {}
+    mouse = np.load(os.path.join(HERE, "dataset.npz"))["mouse_norm"]
+    lat_f, _ = golden_encoder(g, full, sd_f, "full", mouse, rows=[0, 1, 2, 3, 100, 255, 256])
+    del g["full_input"]                      # = dataset.npz mouse_norm
+    golden_detok(g, full, sd_f, "full", lat_f, seed=22)
+    np.savez_compressed(os.path.join(HERE, "full.npz"), **g)
+    for f in ("dataset.npz", "tiny.npz", "full.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
