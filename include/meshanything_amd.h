@@ -1,0 +1,202 @@
+/*
+ * meshanything_amd.h -- C ABI of the MI355X-native MeshAnything inference engine.
+ *
+ * The reference (buaacyw/MeshAnything @ 2024_08_07) has no native layer and no FFI: its hot path sits behind
+ * four Python call boundaries.  Each entry point below names the reference call it
+ * replaces; `meshanything_amd/model.py` re-exposes them under the reference's own Python names
+ * (MeshAnything.forward / point_encoder.encode_latents / transformer.generate / tokenizer(...)).
+ *
+ * Conventions
+ *   - return 0 (MA_OK) on success, a negative MA_ERR_* code on failure; text via ma_last_error().
+ *     No C++ exception crosses this boundary.
+ *   - all tensor arguments are caller-owned DEVICE pointers (row-major, dense) unless marked "host";
+ *     the engine owns weights, KV cache, workspace and the captured hipGraph.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous on that
+ *     stream except where noted (ma_generate / ma_forward read back lengths and therefore synchronise).
+ *   - one engine per device; an engine is not thread-safe.
+ */
+#ifndef MESHANYTHING_AMD_H
+#define MESHANYTHING_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MA_API __attribute__((visibility("default")))
+
+enum {
+    MA_OK = 0,
+    MA_ERR_INVALID = -1,        /* bad argument / config */
+    MA_ERR_HIP = -2,            /* a HIP runtime call failed */
+    MA_ERR_STATE = -3,          /* call made in the wrong state (e.g. weights not loaded) */
+    MA_ERR_UNKNOWN_TENSOR = -4, /* ma_engine_load_weights: key not part of the checkpoint layout */
+    MA_ERR_SHAPE = -5,          /* tensor shape/dtype does not match the layout */
+    MA_ERR_MISSING = -6,        /* ma_engine_finalize_weights: required tensors were never loaded */
+    MA_ERR_NCCL = -7            /* RCCL call failed / librccl not loadable */
+};
+
+/* element types: engine policy (ma_config.dtype: F32 or BF16) and source-tensor dtypes of ma_tensor_desc */
+enum { MA_DTYPE_F32 = 0, MA_DTYPE_BF16 = 1, MA_DTYPE_F16 = 2 };
+
+/* Shape + policy.  Field order mirrors meshanything_amd/config.py::MAConfig (all int32).
+ * Defaults of the 350M checkpoint in comments; reference sources: MeshAnything/miche/shapevae-256.yaml:7-19,
+ * MeshAnything/models/meshanything.py:18,27,88-113, main.py:77-80. */
+typedef struct ma_config {
+    int32_t struct_size;   /* = sizeof(ma_config) */
+    /* point encoder (Michelangelo perceiver) */
+    int32_t n_points;      /* 4096 */
+    int32_t num_freqs;     /* 8    */
+    int32_t enc_width;     /* 768  */
+    int32_t enc_heads;     /* 12   */
+    int32_t num_latents;   /* 256 (+1 shape token = cond_length 257) */
+    int32_t enc_layers;    /* 8    */
+    int32_t shape_layers;  /* 16   */
+    int32_t embed_dim;     /* 64   */
+    /* autoregressive decoder (OPT-350m shape, post-LN, ReLU) */
+    int32_t hidden;        /* 1024 */
+    int32_t heads;         /* 16   */
+    int32_t layers;        /* 24   */
+    int32_t ffn;           /* 4096 */
+    int32_t codebook_size; /* 8192 (vocab = +3: bos 0, eos 1, pad 2) */
+    int32_t codebook_dim;  /* 1024 */
+    int32_t n_max_faces;   /* 800  (max_new_tokens = 9*faces + 2) */
+    int32_t max_positions; /* 18259 (embed_positions has +2 offset rows) */
+    /* detokenizer (BERT-base shape, 6 layers) */
+    int32_t tok_width;     /* 768  */
+    int32_t tok_heads;     /* 12   */
+    int32_t tok_layers;    /* 6    */
+    int32_t tok_ffn;       /* 3072 */
+    int32_t tok_max_pos;   /* 18000 */
+    int32_t discrete_num;  /* 128  */
+    /* engine policy */
+    int32_t max_batch;     /* largest B accepted by encode/generate/detokenize/forward */
+    int32_t dtype;         /* MA_DTYPE_BF16: bf16 weights + KV, GEMM/attention inputs rounded to bf16, fp32 accumulate;
+                              MA_DTYPE_F32: everything fp32 ("exact" mode for the parity gates) */
+    int32_t kv_splits;     /* split-KV factor of the decode attention kernel */
+    int32_t use_graph;     /* 1: replay one captured decode step (hipGraph); 0: eager launches */
+} ma_config;
+
+typedef struct ma_engine ma_engine;
+
+/* One checkpoint tensor, by its key in the reference state dict (main.py:99-104; layout SURVEY.md Appendix A).
+ * `data` is a HOST pointer to a dense row-major array of `dtype`. */
+typedef struct ma_tensor_desc {
+    const char *name;
+    int32_t dtype;          /* MA_DTYPE_F32 | MA_DTYPE_BF16 | MA_DTYPE_F16 */
+    int32_t ndim;           /* 1..3 */
+    int64_t shape[4];
+    const void *data;
+} ma_tensor_desc;
+
+/* Decoding options of transformer.generate(...) as called at meshanything.py:143-162. */
+typedef struct ma_sample_cfg {
+    int32_t struct_size;    /* = sizeof(ma_sample_cfg) */
+    int32_t do_sample;      /* 0: greedy (num_beams=1); 1: top_k -> top_p -> multinomial */
+    int32_t top_k;          /* 50 */
+    float   top_p;          /* 0.95 */
+    int32_t max_new_tokens; /* <= 9*n_max_faces + 2; 0 = that maximum */
+    int32_t suppress_eos;   /* 1: never emit eos (full-length throughput runs on random weights) */
+    int32_t check_every;    /* poll the all-rows-finished flag every this many steps (0 = 64) */
+    int32_t reserved;
+    uint64_t seed;          /* in-kernel uniform stream when `uniforms` is NULL */
+    const float *uniforms;  /* DEVICE (B, max_new_tokens) uniforms in [0,1), or NULL.  Injected uniforms define
+                               sampling parity with the oracle (the reference's Philox stream is not reproducible). */
+} ma_sample_cfg;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------------- */
+MA_API const char *ma_version(void);
+MA_API const char *ma_last_error(const ma_engine *e);      /* e may be NULL: last error of a failed create */
+/* replaces: MeshAnything(args) construction, meshanything.py:83-123 */
+MA_API int  ma_engine_create(ma_engine **out, const ma_config *cfg, int device);
+MA_API void ma_engine_destroy(ma_engine *e);
+/* integer options (debug / A-B switches); see DESIGN.md.  Unknown names -> MA_ERR_INVALID. */
+MA_API int  ma_engine_set_option(ma_engine *e, const char *name, int64_t value);
+
+/* ---- weights ------------------------------------------------------------------------------------------ */
+/* replaces: safe_open(...) + load_state_dict(strict=True), main.py:99-104.  May be called repeatedly with
+ * subsets of the checkpoint; q/k/v projections are fused, matrices converted to the policy dtype.
+ * Keys the hot path never reads (embed_tokens, shape_projection, geo_decoder.*) are accepted and dropped. */
+MA_API int  ma_engine_load_weights(ma_engine *e, const ma_tensor_desc *tensors, int n);
+/* strict=True check: every tensor the hot path needs has been loaded */
+MA_API int  ma_engine_finalize_weights(ma_engine *e);
+/* the packed device weight arena (for a collective broadcast driven from the host framework) */
+MA_API int  ma_engine_arena(ma_engine *e, void **dev_ptr, size_t *bytes);
+/* declare the arena valid after it was filled by a broadcast (ranks != root) */
+MA_API int  ma_engine_mark_weights_loaded(ma_engine *e);
+/* replaces: accelerate.prepare(model) -> DDP initial parameter broadcast, main.py:113-118,146.
+ * `nccl_comm` is an ncclComm_t (RCCL); one ncclBroadcast of the arena over xGMI; no per-step collectives. */
+MA_API int  ma_engine_broadcast_weights(ma_engine *e, void *nccl_comm, int root, void *stream);
+
+/* host-only arena description (no GPU needed): layout is a pure function of the config */
+MA_API int64_t ma_arena_bytes(const ma_config *cfg);
+MA_API int     ma_arena_num_entries(const ma_config *cfg);
+MA_API int     ma_arena_entry(const ma_config *cfg, int i, char *name, int name_cap, int64_t *offset,
+                              int64_t *bytes, int32_t *dtype, int32_t *rows, int32_t *cols);
+/* host-only packing of checkpoint tensors into a caller-provided host arena of ma_arena_bytes() bytes
+ * (same conversion/fusion as ma_engine_load_weights); ma_engine_upload_arena copies it to the device. */
+MA_API int  ma_pack_weights_host(const ma_config *cfg, const ma_tensor_desc *tensors, int n, void *host_arena,
+                                 char *err, int err_cap);
+MA_API int  ma_engine_upload_arena(ma_engine *e, const void *host_arena, size_t bytes);
+
+/* ---- the hot path ------------------------------------------------------------------------------------- */
+/* replaces: point_encoder.encode_latents(pc_normal) (asl_pl_module.py:145-157) and
+ * MeshAnything.process_point_feature (meshanything.py:125-132, which calls to_shape_latents).
+ *   pc       (B, n_points, 6) xyz+normal, `pc_dtype` F32 or F16 (Dataset yields fp16, main.py:56)
+ *   latents  (B, cond_length, enc_width) fp32  -- raw encoder latents (the detokenizer's point_feature)
+ *   prefix   (B, cond_length, hidden) fp32     -- decoder prefix (may be NULL to skip)              */
+MA_API int  ma_encode(ma_engine *e, const void *pc, int pc_dtype, int B, float *latents, float *prefix, void *stream);
+
+/* replaces: transformer.generate(inputs_embeds=prefix, max_new_tokens=..., ...) (meshanything.py:143-162).
+ *   tokens      (B, max_new_tokens) int64 device: new tokens only; finished rows padded with pad=2
+ *   lengths     host (B): tokens generated per row including its eos
+ *   n_generated host: number of valid columns (= max over rows; what generate() would return as shape[1])
+ * Synchronises `stream` before returning. */
+MA_API int  ma_generate(ma_engine *e, const float *prefix, int B, const ma_sample_cfg *sc, int64_t *tokens,
+                        int32_t *lengths, int32_t *n_generated, void *stream);
+
+/* replaces: meshanything.py:163-172 (eos-pad to 9F+2, drop first/last, specials -> -1, others -= 3).
+ *   tokens (B, max_new_tokens) + n_generated  ->  ids (B, 9*n_max_faces) int64 in [-1, codebook_size) */
+MA_API int  ma_postprocess_tokens(ma_engine *e, const int64_t *tokens, int B, int n_generated, int64_t *ids, void *stream);
+
+/* replaces: get_codes (meshanything.py:178-212) + tokenizer(ids, codes, point_feature=latents) (50-80).
+ *   coords (B, n_max_faces, 3, 3) fp32, NaN rows = invalid faces */
+MA_API int  ma_detokenize(ma_engine *e, const int64_t *ids, const float *latents, int B, float *coords, void *stream);
+
+/* replaces: MeshAnything.forward(pc_normal, sampling) (meshanything.py:134-176): encode -> generate ->
+ * postprocess -> detokenize.  `tokens` / `ids` / `latents` may be NULL.  Synchronises. */
+MA_API int  ma_forward(ma_engine *e, const void *pc, int pc_dtype, int B, const ma_sample_cfg *sc, float *coords,
+                       int64_t *tokens, int32_t *lengths, int32_t *n_generated, int64_t *ids, float *latents, void *stream);
+
+/* ---- kernel-level entry points (parity tests and microbenchmarks call the same kernels the engine runs) */
+enum { MA_ACT_NONE = 0, MA_ACT_RELU = 1, MA_ACT_GELU = 2 };
+/* y[N] = act(W[N,K] . norm(x)[K] + bias) + res ; optional LayerNorm prologue on x (ln_g != NULL); wdtype F32|BF16.
+ * With wdtype BF16, x is rounded to bf16 after the prologue (the engine's bf16 policy). */
+MA_API int  ma_op_gemv(int wdtype, const void *W, const float *bias, const float *x, const float *ln_g, const float *ln_b,
+                       float ln_eps, const float *res, float *y, float *xn_out, int N, int K, int act, void *stream);
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + R[M,N]; K % 32 == 0; impl 0 = MFMA, 1 = plain VALU reference kernel */
+MA_API int  ma_op_gemm(int wdtype, int impl, const float *A, int lda, const void *W, const float *bias, const float *R, int ldr,
+                       float *C, int ldc, int M, int N, int K, int act, void *stream);
+MA_API int  ma_op_layernorm(const float *x, int ldx, const float *g, const float *b, float eps, float *y, int ldy,
+                            int rows, int D, void *stream);
+/* O[b,q,h*64+d] = softmax(Q K^T * scale) V, head_dim 64, fp32 in/out; strides in elements; round_bf16 rounds q,k,v */
+MA_API int  ma_op_attention(const float *Q, int q_rs, int q_hs, const float *K, int k_rs, int k_hs, const float *V, int v_rs,
+                            int v_hs, float *O, int o_rs, int Sq, int Sk, int H, float scale, int causal_offset /* <0: none */,
+                            int round_bf16, void *stream);
+/* single-query attention over a KV cache laid out (H, max_seq, 64) of kvdtype; len = number of cached positions */
+MA_API int  ma_op_decode_attention(int kvdtype, const float *q, const void *kcache, const void *vcache, int H, int max_seq,
+                                   int len, int splits, float *out, void *workspace /* >= splits*H*66 floats */, void *stream);
+
+/* ---- measurement --------------------------------------------------------------------------------------- */
+/* Time the decode-step kernels with HIP events on `stream`: runs `steps` decode steps eagerly at KV length
+ * `kv_len` (cache contents arbitrary) and reports, per kernel class, launches and summed event-bracketed ms.
+ * Classes: 0 gemv (all weight-streaming launches), 1 decode attention, 2 attention combine, 3 pick/sample. */
+typedef struct ma_kernel_timing { int32_t launches[8]; float ms[8]; float step_ms_graph; float step_ms_eager; } ma_kernel_timing;
+MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_timing *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHANYTHING_AMD_H */

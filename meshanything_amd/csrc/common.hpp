@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ma {
+
+constexpr int WAVE = 64;
+constexpr int HEAD_DIM = 64;
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 bits, round-to-nearest-even (NaN kept quiet).  Matches torch .to(bfloat16) and checkpoint.bf16_round.
+__host__ __device__ inline bf16_t f2bf(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf2f(bf16_t b) {
+    union { float f; uint32_t u; } v; v.u = ((uint32_t)b) << 16; return v.f;
+}
+// fp32 -> nearest bf16 value, returned as fp32
+__device__ inline float round_bf16(float f) { return bf2f(f2bf(f)); }
+
+__host__ inline float half2float_host(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else { int e = -1; do { e++; man <<= 1; } while (!(man & 0x400u)); man &= 0x3ffu; u = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13); }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp + 112u) << 23) | (man << 13);
+    union { float f; uint32_t u; } v; v.u = u; return v.f;
+}
+
+// two bf16 packed in one dword -> two floats (element 0 in the low half)
+__device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over aligned groups of G lanes (G power of two <= 64); every lane of the group gets the sum
+template <int G>
+__device__ inline float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact (erf) GELU, as torch.nn.GELU() / HF "gelu"
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+__device__ inline float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_GELU) return gelu_erf(v);
+    return v;
+}
+
+// 16-byte streaming load (weights / KV are read once per launch: keep them out of the way of the small hot vectors)
+__device__ inline u32x4 ld_stream16(const void* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+// better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
+__device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+}  // namespace ma

@@ -1,0 +1,926 @@
+// MeshAnything inference engine for MI355X (gfx950): host side + C ABI (include/meshanything_amd.h).
+//
+// Phases (reference: MeshAnything.forward, MeshAnything/models/meshanything.py:134-176):
+//   encode      point cloud -> 257x768 latents -> 257x1024 prefix        (MFMA GEMMs + LDS-tiled attention)
+//   prefill     24 OPT layers over the prefix, fills the KV cache        (same kernels, causal)
+//   decode      <= 7201 steps, each = 147 launches replayed from ONE hipGraph (weight-streaming GEMVs + split-KV attention);
+//               all step-varying scalars live in a device DecState, so the graph never changes
+//   detokenize  codebook gather + 6 BERT layers over 1057 tokens + per-coordinate argmax
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <exception>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/meshanything_amd.h"
+#include "attn.hpp"
+#include "attn_decode.hpp"
+#include "common.hpp"
+#include "gemm.hpp"
+#include "gemv.hpp"
+#include "misc.hpp"
+#include "state.hpp"
+#include "weights.hpp"
+
+using namespace ma;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct MaError : std::exception {
+    int code; std::string msg;
+    MaError(int c, std::string m) : code(c), msg(std::move(m)) {}
+    const char* what() const noexcept override { return msg.c_str(); }
+};
+
+#define HIP_CHECK(expr)                                                                                      \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw MaError(MA_ERR_HIP, std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct DecLayerPtrs {
+    const void *qkv_w, *o_w, *fc1_w, *fc2_w;
+    const float *qkv_b, *o_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+}  // namespace
+
+struct ma_engine {
+    ma_config cfg{};
+    int device = 0;
+    Layout L;
+    PackState ps;
+    bool weights_ready = false;
+    std::string err;
+    char* arena = nullptr;
+
+    int T = 0, V = 0, maxnew = 0, maxseq = 0, nf = 0, S = 0;
+    bool bf16 = true;
+    size_t kv_elem = 2;
+    char* kv = nullptr;              // [layers][2][heads][maxseq][64] of KT
+    size_t kv_plane = 0;             // bytes of one K (or V) plane of one layer
+
+    // decode-step buffers
+    float *d_e = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_ypre1 = nullptr, *d_ypre2 = nullptr, *d_h0 = nullptr, *d_h1 = nullptr,
+          *d_ffn = nullptr, *d_logits = nullptr, *d_part = nullptr, *d_pval = nullptr;
+    int* d_pidx = nullptr;
+    int n_parts = 0;
+    DecState* d_st = nullptr;
+    long long* d_tokens = nullptr;
+    int* h_flag = nullptr;           // pinned
+    long long* h_tokens = nullptr;   // pinned (maxnew)
+    std::vector<DecLayerPtrs> dl;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the caller's may be the legacy null stream)
+
+    // dense-phase workspace (one sample at a time)
+    std::vector<void*> allocs;
+    float *w_feat = nullptr, *w_data = nullptr, *w_dataln = nullptr, *w_kv = nullptr, *w_a = nullptr, *w_b = nullptr, *w_c = nullptr,
+          *w_qkv = nullptr, *w_mlp = nullptr, *w_lat = nullptr, *w_cat = nullptr, *w_mean = nullptr;
+    float *w_x = nullptr, *w_fein = nullptr, *w_fe = nullptr, *w_logit = nullptr;
+    unsigned char* w_mask = nullptr;
+    float *w_latents = nullptr, *w_prefix = nullptr, *w_coords = nullptr;   // ma_forward intermediates (max_batch rows)
+    long long *w_tokens = nullptr, *w_ids = nullptr;
+
+    // options
+    int opt_gemm_impl = 0;           // 0 MFMA, 1 VALU reference kernel
+    int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
+
+    template <typename Tp> Tp* dmalloc(size_t n) {
+        void* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(Tp)));
+        allocs.push_back(p);
+        return reinterpret_cast<Tp*>(p);
+    }
+    const void* P(const std::string& name) const {
+        auto it = L.entry_by_name.find(name);
+        if (it == L.entry_by_name.end()) throw MaError(MA_ERR_INVALID, "internal: no arena entry " + name);
+        return arena + L.entries[it->second].offset;
+    }
+    const float* PF(const std::string& name) const { return reinterpret_cast<const float*>(P(name)); }
+    char* kplane(int layer) const { return kv + (size_t)(2 * layer) * kv_plane; }
+    char* vplane(int layer) const { return kv + (size_t)(2 * layer + 1) * kv_plane; }
+};
+
+namespace {
+
+const std::string SM = "point_encoder.model.shape_model.", DEC = "transformer.model.decoder.", TOK = "tokenizer.";
+
+// ------------------------------------------------------------------------------------------------ launch helpers
+void gemm(ma_engine* e, hipStream_t s, const float* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr,
+          float* C, int ldc, int M, int act, int n_override = 0) {
+    const Entry& en = e->L.get(w);
+    GemmArgs g{A, lda, e->arena + en.offset, bias_name ? e->PF(bias_name) : nullptr, R, ldr, C, ldc, M, n_override ? n_override : en.rows, en.cols, act};
+    hipError_t r = e->bf16 ? launch_gemm<bf16_t>(g, e->opt_gemm_impl, s) : launch_gemm<float>(g, e->opt_gemm_impl, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, "gemm launch failed for " + w + ": " + hipGetErrorString(r));
+}
+void gemm(ma_engine* e, hipStream_t s, const float* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr,
+          float* C, int ldc, int M, int act) {
+    gemm(e, s, A, lda, w, b.c_str(), R, ldr, C, ldc, M, act);
+}
+void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y, int ldy, int rows, int D,
+            const char* wkey = "weight", const char* bkey = "bias") {
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, e->PF(prefix + wkey), e->PF(prefix + bkey), eps, y, ldy, rows, D);
+    HIP_CHECK(hipGetLastError());
+}
+void attention(ma_engine* e, hipStream_t s, const float* Q, int q_rs, int q_hs, const float* K, int k_rs, int k_hs, const float* Vp, int v_rs,
+               int v_hs, float* O, int o_rs, int Sq, int Sk, int H, int causal_offset) {
+    AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 1 : 0};
+    HIP_CHECK(launch_attention(a, s));
+}
+void copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int rows, int cols) {
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    HIP_CHECK(hipGetLastError());
+}
+void add_rows(hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
+              float* out, int ld_out, int rows, int cols) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out, ld_out, rows, cols);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------ point encoder
+// ResidualAttentionBlock (transformer_blocks.py:109-112): x += proj(attn(c_qkv(ln_1 x))); x += mlp(ln_2 x).  x: (rows, W) in place.
+void miche_block(ma_engine* e, hipStream_t s, float* x, int rows, const std::string& p) {
+    const int W = e->cfg.enc_width, Hh = e->cfg.enc_heads;
+    lnrows(e, s, x, W, p + "ln_1.", 1e-5f, e->w_a, W, rows, W);
+    gemm(e, s, e->w_a, W, p + "attn.c_qkv.weight", nullptr, nullptr, 0, e->w_qkv, 3 * W, rows, ACT_NONE);
+    // per-head interleaved [q|k|v] (transformer_blocks.py:61-62): head stride 192, k at +64, v at +128
+    attention(e, s, e->w_qkv, 3 * W, 192, e->w_qkv + 64, 3 * W, 192, e->w_qkv + 128, 3 * W, 192, e->w_b, W, rows, rows, Hh, -1);
+    gemm(e, s, e->w_b, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", x, W, x, W, rows, ACT_NONE);
+    lnrows(e, s, x, W, p + "ln_2.", 1e-5f, e->w_a, W, rows, W);
+    gemm(e, s, e->w_a, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, e->w_mlp, 4 * W, rows, ACT_GELU);
+    gemm(e, s, e->w_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", x, W, x, W, rows, ACT_NONE);
+}
+
+// encode_latents (asl_pl_module.py:145-157 -> sal_perceiver.py:372-381 -> 74-99) for ONE sample -> latents (T, W)
+void encode_one(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, float* latents) {
+    const ma_config& c = e->cfg;
+    const int N = c.n_points, W = c.enc_width, T = e->T, Hh = c.enc_heads;
+    if (pc_dtype == MA_DTYPE_F16)
+        hipLaunchKernelGGL((fourier_kernel<_Float16>), dim3(ceil_div(N * 64, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), N, c.num_freqs, e->w_feat, 64);
+    else
+        hipLaunchKernelGGL((fourier_kernel<float>), dim3(ceil_div(N * 64, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), N, c.num_freqs, e->w_feat, 64);
+    HIP_CHECK(hipGetLastError());
+    gemm(e, s, e->w_feat, 64, SM + "encoder.input_proj.weight", SM + "encoder.input_proj.bias", nullptr, 0, e->w_data, W, N, ACT_NONE);
+    const std::string p = SM + "encoder.cross_attn.";
+    const float* query = e->PF(SM + "encoder.query");
+    // x = query + attn(ln_1 query, ln_2 data); x += mlp(ln_3 x)     (transformer_blocks.py:223-226)
+    lnrows(e, s, query, W, p + "ln_1.", 1e-5f, e->w_a, W, T, W);
+    gemm(e, s, e->w_a, W, p + "attn.c_q.weight", nullptr, nullptr, 0, e->w_b, W, T, ACT_NONE);
+    lnrows(e, s, e->w_data, W, p + "ln_2.", 1e-5f, e->w_dataln, W, N, W);
+    gemm(e, s, e->w_dataln, W, p + "attn.c_kv.weight", nullptr, nullptr, 0, e->w_kv, 2 * W, N, ACT_NONE);
+    // kv viewed (N, heads, 128) split [k|v] (transformer_blocks.py:172-174)
+    attention(e, s, e->w_b, W, 64, e->w_kv, 2 * W, 128, e->w_kv + 64, 2 * W, 128, e->w_c, W, T, N, Hh, -1);
+    gemm(e, s, e->w_c, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", query, W, e->w_lat, W, T, ACT_NONE);
+    lnrows(e, s, e->w_lat, W, p + "ln_3.", 1e-5f, e->w_a, W, T, W);
+    gemm(e, s, e->w_a, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, e->w_mlp, 4 * W, T, ACT_GELU);
+    gemm(e, s, e->w_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", e->w_lat, W, e->w_lat, W, T, ACT_NONE);
+    for (int n = 0; n < c.enc_layers; ++n) miche_block(e, s, e->w_lat, T, SM + "encoder.self_attn.resblocks." + std::to_string(n) + ".");
+    lnrows(e, s, e->w_lat, W, SM + "encoder.ln_post.", 1e-5f, latents, W, T, W);
+}
+
+// process_point_feature (meshanything.py:125-132) incl. to_shape_latents (asl_pl_module.py:182-185) for ONE sample
+void prefix_one(ma_engine* e, hipStream_t s, const float* latents, float* prefix) {
+    const ma_config& c = e->cfg;
+    const int W = c.enc_width, T = e->T, H = c.hidden, E = c.embed_dim, NL = c.num_latents;
+    const float* lat1 = latents + W;                                       // point_feature[:, 1:]
+    gemm(e, s, lat1, W, SM + "pre_kl.weight", SM + "pre_kl.bias", nullptr, 0, e->w_mean, E, NL, ACT_NONE);     // posterior.mode()
+    gemm(e, s, e->w_mean, E, SM + "post_kl.weight", SM + "post_kl.bias", nullptr, 0, e->w_lat, W, NL, ACT_NONE);
+    for (int n = 0; n < c.shape_layers; ++n) miche_block(e, s, e->w_lat, NL, SM + "transformer.resblocks." + std::to_string(n) + ".");
+    copy2d(s, lat1, W, e->w_cat, 2 * W, NL, W);                            // cat([latents, shape_latents], -1)
+    copy2d(s, e->w_lat, W, e->w_cat + W, 2 * W, NL, W);
+    gemm(e, s, latents, W, "cond_head_proj.weight", "cond_head_proj.bias", nullptr, 0, prefix, H, 1, ACT_NONE);
+    gemm(e, s, e->w_cat, 2 * W, "cond_proj.weight", "cond_proj.bias", nullptr, 0, prefix + H, H, NL, ACT_NONE);
+    (void)T;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+template <typename WT>
+void gemv_launch(const GemvArgs& a, hipStream_t s) {
+    hipError_t r = launch_gemv<WT>(a, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
+}
+void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s) { if (e->bf16) gemv_launch<bf16_t>(a, s); else gemv_launch<float>(a, s); }
+
+struct StepTimer {                    // optional per-launch HIP events (ma_profile_decode)
+    std::vector<hipEvent_t>* ev = nullptr;
+    std::vector<int>* cls = nullptr;
+    hipStream_t s = nullptr;
+    void begin(int c) { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); cls->push_back(c); } }
+    void end() { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); } }
+};
+
+GemvArgs gemv_base(ma_engine* e) {
+    GemvArgs a{};
+    a.round_x = e->bf16 ? 1 : 0;
+    a.st = e->d_st;
+    a.act = ACT_NONE;
+    a.epi = EPI_PLAIN;
+    return a;
+}
+
+// one OPT layer of one decode step.  `x_in` = this layer's input before its (optional) LayerNorm prologue.
+void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden;
+    const DecLayerPtrs& w = e->dl[l];
+    const float* resid = ln_g ? e->d_h0 : x_in;
+    {   // q,k,v = W h + b ; k,v appended to the cache in place ([3p] OPTAttention; 4.39.3 grows it with torch.cat)
+        GemvArgs a = gemv_base(e);
+        a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? e->d_h0 : nullptr;
+        a.y = e->d_q; a.N = 3 * H; a.K = H; a.epi = EPI_QKV; a.kcache = e->kplane(l); a.vcache = e->vplane(l); a.H = H; a.max_seq = e->maxseq;
+        tm.begin(0); gemv(e, a, s); tm.end();
+    }
+    tm.begin(1);
+    if (e->bf16)
+        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(c.kv_splits, c.heads), dim3(256), 0, s, e->d_q, reinterpret_cast<const bf16_t*>(e->kplane(l)),
+                           reinterpret_cast<const bf16_t*>(e->vplane(l)), e->maxseq, e->d_st, len_override, 1, e->d_part);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(c.kv_splits, c.heads), dim3(256), 0, s, e->d_q, reinterpret_cast<const float*>(e->kplane(l)),
+                           reinterpret_cast<const float*>(e->vplane(l)), e->maxseq, e->d_st, len_override, 0, e->d_part);
+    HIP_CHECK(hipGetLastError());
+    tm.end();
+    tm.begin(2);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(c.heads), dim3(64), 0, s, e->d_part, c.kv_splits, e->d_attn);
+    HIP_CHECK(hipGetLastError());
+    tm.end();
+    {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
+        GemvArgs a = gemv_base(e);
+        a.W = w.o_w; a.bias = w.o_b; a.x = e->d_attn; a.res = resid; a.y = e->d_ypre1; a.N = H; a.K = H;
+        tm.begin(0); gemv(e, a, s); tm.end();
+    }
+    {   // f = relu(W1 LN1(y1) + b1); h1 = LN1(y1) kept for the residual
+        GemvArgs a = gemv_base(e);
+        a.W = w.fc1_w; a.bias = w.fc1_b; a.x = e->d_ypre1; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = e->d_h1;
+        a.y = e->d_ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
+        tm.begin(0); gemv(e, a, s); tm.end();
+    }
+    {   // y2 = h1 + W2 f + b2
+        GemvArgs a = gemv_base(e);
+        a.W = w.fc2_w; a.bias = w.fc2_b; a.x = e->d_ffn; a.res = e->d_h1; a.y = e->d_ypre2; a.N = H; a.K = c.ffn;
+        tm.begin(0); gemv(e, a, s); tm.end();
+    }
+}
+
+void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, const float* ln_g, const float* ln_b, StepTimer& tm) {
+    GemvArgs a = gemv_base(e);
+    a.W = e->P("transformer.lm_head.weight"); a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+    a.y = e->d_logits; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD; a.part_val = e->d_pval; a.part_idx = e->d_pidx;
+    tm.begin(0); gemv(e, a, s); tm.end();
+}
+
+void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm) {
+    tm.begin(3);
+    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(256), (size_t)e->V * sizeof(float), s, e->d_logits, e->V, e->d_pval, e->d_pidx, e->n_parts, e->d_st, e->d_tokens, e->T);
+    HIP_CHECK(hipGetLastError());
+    tm.end();
+}
+
+// One full decode step (shape_opt.py:318-328 embedding branch -> 24 layers -> lm_head -> pick).  Replayable: no host-side
+// step-dependent argument.
+void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTimer& tm) {
+    const ma_config& c = e->cfg;
+    {
+        GemvArgs a = gemv_base(e);
+        a.W = e->P(DEC + "input_layer.weight"); a.bias = e->PF(DEC + "input_layer.bias"); a.y = e->d_e; a.N = c.hidden; a.K = c.codebook_dim;
+        a.epi = EPI_EMBED; a.codebook = e->PF(DEC + "quantize_codebooks"); a.extra = e->PF(DEC + "extra_embeds.weight");
+        a.tokpos = e->PF(DEC + "token_embed_positions.weight"); a.cond = e->PF(DEC + "cond_embed.weight");
+        a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
+        tm.begin(0); gemv(e, a, s); tm.end();
+    }
+    for (int l = 0; l < c.layers; ++l) {
+        if (l == 0) enqueue_layer(e, s, 0, e->d_e, nullptr, nullptr, len_override, tm);
+        else enqueue_layer(e, s, l, e->d_ypre2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm);
+    }
+    enqueue_lm_head(e, s, e->d_ypre2, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm);
+    enqueue_pick(e, s, tm);
+}
+
+void ensure_graph(ma_engine* e, hipStream_t) {
+    if (e->gexec || !e->cfg.use_graph) return;
+    StepTimer none;
+    if (!e->cap_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    hipStream_t s = e->cap_stream;
+    HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    try {
+        enqueue_decode_step(e, s, -1, none);
+    } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(s, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(s, &e->graph));
+    HIP_CHECK(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+}
+
+void launch_step(ma_engine* e, hipStream_t s) {
+    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec, s));
+    else { StepTimer none; enqueue_decode_step(e, s, -1, none); }
+}
+
+// prefill: ShapeOPTDecoder.forward inputs_embeds branch (shape_opt.py:331-364) + 24 post-LN layers, causal, on the T prefix rows
+void prefill(ma_engine* e, hipStream_t s, const float* prefix) {
+    const ma_config& c = e->cfg;
+    const int T = e->T, H = c.hidden;
+    StepTimer none;
+    float* h = e->w_x;                       // (T, H)
+    add_rows(s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, T, H);
+    if (e->opt_prefill_stepwise) {
+        // debug path: feed the prefix rows through the decode-step kernels one position at a time
+        for (int j = 0; j < T; ++j) {
+            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, 0, j, 0);
+            HIP_CHECK(hipGetLastError());
+            for (int l = 0; l < c.layers; ++l) {
+                if (l == 0) enqueue_layer(e, s, 0, h + (size_t)j * H, nullptr, nullptr, -1, none);
+                else enqueue_layer(e, s, l, e->d_ypre2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, -1, none);
+            }
+        }
+        enqueue_lm_head(e, s, e->d_ypre2, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, none);
+        return;
+    }
+    float* qkv = e->w_qkv;                   // (T, 3H)
+    float* att = e->w_b;                     // (T, H)
+    float* y = e->w_c;                       // (T, H)
+    float* ffn = e->w_mlp;                   // (T, ffn)
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = DEC + "layers." + std::to_string(l) + ".";
+        gemm(e, s, h, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * H, T, ACT_NONE);
+        const int n = T * c.heads * 64;
+        if (e->bf16) hipLaunchKernelGGL((kv_fill_kernel<bf16_t>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+                                        reinterpret_cast<bf16_t*>(e->kplane(l)), reinterpret_cast<bf16_t*>(e->vplane(l)));
+        else hipLaunchKernelGGL((kv_fill_kernel<float>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+                                reinterpret_cast<float*>(e->kplane(l)), reinterpret_cast<float*>(e->vplane(l)));
+        HIP_CHECK(hipGetLastError());
+        attention(e, s, qkv, 3 * H, 64, qkv + H, 3 * H, 64, qkv + 2 * H, 3 * H, 64, att, H, T, T, c.heads, 0);
+        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, y, H, T, ACT_NONE);
+        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, T, H);
+        gemm(e, s, h, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, ffn, c.ffn, T, ACT_RELU);
+        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, y, H, T, ACT_NONE);
+        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, T, H);
+    }
+    // only the last prefix row feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
+    enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, nullptr, nullptr, none);
+}
+
+void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int row, int maxn) {
+    DecState st{};
+    st.t = 0; st.pos = e->T - 1; st.cur_tok = 0; st.finished = 0;
+    st.suppress_eos = sc.suppress_eos; st.do_sample = sc.do_sample; st.top_k = sc.top_k; st.top_p = sc.top_p;
+    st.seed = sc.seed; st.uniforms = sc.uniforms ? sc.uniforms + (size_t)row * maxn : nullptr; st.row = row; st.max_new = maxn;
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, e->d_st, st);
+    HIP_CHECK(hipGetLastError());
+}
+
+ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
+    ma_sample_cfg r{};
+    r.struct_size = sizeof(ma_sample_cfg);
+    r.top_k = 50; r.top_p = 0.95f;
+    if (sc) {
+        if (sc->struct_size != (int32_t)sizeof(ma_sample_cfg)) throw MaError(MA_ERR_INVALID, "ma_sample_cfg.struct_size mismatch");
+        r = *sc;
+    }
+    if (r.max_new_tokens <= 0 || r.max_new_tokens > e->maxnew) {
+        if (r.max_new_tokens > e->maxnew) throw MaError(MA_ERR_INVALID, "max_new_tokens exceeds 9*n_max_faces+2");
+        r.max_new_tokens = e->maxnew;
+    }
+    if (r.check_every <= 0) r.check_every = 64;
+    if (r.do_sample && (r.top_k < 1 || r.top_k > PICK_KMAX)) throw MaError(MA_ERR_INVALID, "top_k must be in [1,64]");
+    if (r.do_sample && !(r.top_p > 0.f && r.top_p <= 1.f)) throw MaError(MA_ERR_INVALID, "top_p must be in (0,1]");
+    return r;
+}
+
+// generate() for ONE row: prefill, then step until eos / max_new_tokens.  Returns the row's length (incl. eos).
+int generate_one(ma_engine* e, hipStream_t s, const float* prefix, const ma_sample_cfg& sc, int row, long long* tokens_row) {
+    const int maxn = sc.max_new_tokens;
+    hipLaunchKernelGGL(fill_tokens_kernel, dim3(ceil_div(e->maxnew, 256)), dim3(256), 0, s, e->d_tokens, (long long)TOK_PAD, e->maxnew);
+    HIP_CHECK(hipGetLastError());
+    ensure_graph(e, s);
+    init_state(e, s, sc, row, maxn);
+    prefill(e, s, prefix);
+    StepTimer none;
+    if (e->opt_prefill_stepwise) init_state(e, s, sc, row, maxn);       // the stepwise prefill used the state's pos field
+    enqueue_pick(e, s, none);                                          // token 0 (expected bos; dropped later, meshanything.py:166)
+    int produced = 1;
+    bool finished = false;
+    while (produced < maxn && !finished) {
+        const int burst = std::min(sc.check_every, maxn - produced);
+        for (int i = 0; i < burst; ++i) launch_step(e, s);
+        produced += burst;
+        HIP_CHECK(hipMemcpyAsync(e->h_flag, &e->d_st->finished, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        finished = *e->h_flag != 0;
+    }
+    HIP_CHECK(hipMemcpyAsync(e->h_tokens, e->d_tokens, (size_t)maxn * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    int len = produced;
+    for (int i = 0; i < produced; ++i) if (e->h_tokens[i] == TOK_EOS) { len = i + 1; break; }
+    HIP_CHECK(hipMemcpyAsync(tokens_row, e->d_tokens, (size_t)e->maxnew * sizeof(long long), hipMemcpyDeviceToDevice, s));
+    return len;
+}
+
+// ------------------------------------------------------------------------------------------------ detokenizer
+void detok_one(ma_engine* e, hipStream_t s, const long long* ids, const float* latents, float* coords) {
+    const ma_config& c = e->cfg;
+    const int W = c.enc_width, T = e->T, Wt = c.tok_width, nf = e->nf, S = e->S, D = c.codebook_dim, Hh = c.tok_heads;
+    float* X = e->w_x;                                               // (S, Wt)
+    // process_point_feature (meshanything.py:42-48)
+    gemm(e, s, latents, W, TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias", nullptr, 0, e->w_a, Wt, 1, ACT_NONE);
+    gemm(e, s, latents + W, W, TOK + "cond_proj.weight", TOK + "cond_proj.bias", nullptr, 0, e->w_a + Wt, Wt, T - 1, ACT_NONE);
+    add_rows(s, e->w_a, Wt, nullptr, nullptr, e->PF(TOK + "point_pe.weight"), Wt, 0, e->w_a, Wt, T, Wt);
+    lnrows(e, s, e->w_a, Wt, TOK + "point_layernorm.", 1e-5f, X, Wt, T, Wt);
+    // faces (meshanything.py:53-60): codes -> project_down -> zero masked -> + pos -> LN
+    hipLaunchKernelGGL(codes_gather_kernel, dim3(ceil_div(nf * 3 * D, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, nf, e->w_fein, e->w_mask);
+    HIP_CHECK(hipGetLastError());
+    gemm(e, s, e->w_fein, 3 * D, TOK + "project_down_codebook.weight", TOK + "project_down_codebook.bias", nullptr, 0, e->w_fe, Wt, nf, ACT_NONE);
+    add_rows(s, e->w_fe, Wt, e->w_mask, nullptr, e->PF(TOK + "pos_embedding.weight"), Wt, 0, e->w_fe, Wt, nf, Wt);
+    lnrows(e, s, e->w_fe, Wt, TOK + "layernorm.", 1e-5f, X + (size_t)T * Wt, Wt, nf, Wt);
+    // 6 BERT post-LN layers, bidirectional, NO mask: padding faces take part as LN(pos_embedding[i]) tokens
+    float* qkv = e->w_qkv; float* att = e->w_b; float* y = e->w_c; float* ffn = e->w_mlp;
+    for (int n = 0; n < c.tok_layers; ++n) {
+        const std::string p = TOK + "decoder.layer." + std::to_string(n) + ".";
+        gemm(e, s, X, Wt, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * Wt, S, ACT_NONE);
+        attention(e, s, qkv, 3 * Wt, 64, qkv + Wt, 3 * Wt, 64, qkv + 2 * Wt, 3 * Wt, 64, att, Wt, S, S, Hh, -1);
+        gemm(e, s, att, Wt, p + "attention.output.dense.weight", p + "attention.output.dense.bias", X, Wt, y, Wt, S, ACT_NONE);
+        lnrows(e, s, y, Wt, p + "attention.output.LayerNorm.", 1e-12f, X, Wt, S, Wt);
+        gemm(e, s, X, Wt, p + "intermediate.dense.weight", p + "intermediate.dense.bias", nullptr, 0, ffn, c.tok_ffn, S, ACT_GELU);
+        gemm(e, s, ffn, c.tok_ffn, p + "output.dense.weight", p + "output.dense.bias", X, Wt, y, Wt, S, ACT_NONE);
+        lnrows(e, s, y, Wt, p + "output.LayerNorm.", 1e-12f, X, Wt, S, Wt);
+    }
+    float* decoded = X + (size_t)T * Wt;                              // last_hidden_state[:, cond_length:]
+    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3(ceil_div(nf * Wt, 256)), dim3(256), 0, s, decoded, Wt, e->w_mask, nf, Wt);
+    HIP_CHECK(hipGetLastError());
+    gemm(e, s, decoded, Wt, TOK + "to_coor_logits.0.weight", TOK + "to_coor_logits.0.bias", nullptr, 0, e->w_logit, 9 * c.discrete_num, nf, ACT_NONE);
+    hipLaunchKernelGGL(coords_argmax_kernel, dim3(ceil_div(nf * 9, 4)), dim3(256), 0, s, e->w_logit, nf, c.discrete_num, e->w_mask, coords);
+    HIP_CHECK(hipGetLastError());
+}
+
+void require_ready(ma_engine* e) {
+    if (!e->weights_ready) throw MaError(MA_ERR_STATE, "weights are not loaded (ma_engine_load_weights + ma_engine_finalize_weights, or ma_engine_mark_weights_loaded)");
+}
+void check_batch(ma_engine* e, int B) {
+    if (B < 1 || B > e->cfg.max_batch) throw MaError(MA_ERR_INVALID, "batch size " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(e->cfg.max_batch) + "]");
+}
+
+void validate_config(const ma_config& c) {
+    auto bad = [](const std::string& m) { throw MaError(MA_ERR_INVALID, "ma_config: " + m); };
+    if (c.struct_size != (int32_t)sizeof(ma_config)) bad("struct_size mismatch (header/library version skew)");
+    if (c.enc_width != c.enc_heads * 64 || c.hidden != c.heads * 64 || c.tok_width != c.tok_heads * 64) bad("head_dim must be 64 (width = heads*64)");
+    if (c.codebook_dim != c.hidden) bad("codebook_dim must equal hidden (word_embed_proj_dim is forced to hidden_size, meshanything.py:112-113)");
+    if (c.dtype != MA_DTYPE_F32 && c.dtype != MA_DTYPE_BF16) bad("dtype must be MA_DTYPE_F32 or MA_DTYPE_BF16");
+    const int dims[] = {c.enc_width, c.hidden, c.ffn, c.tok_width, c.tok_ffn, c.embed_dim, c.codebook_dim};
+    for (int d : dims) if (d <= 0 || d % 32) bad("GEMM dimensions must be positive multiples of 32");
+    if (3 * (2 * c.num_freqs + 1) + 3 > 64 || c.num_freqs < 1 || c.num_freqs > 20) bad("num_freqs out of range");
+    if (c.n_points < 1 || c.num_latents < 1 || c.layers < 1 || c.enc_layers < 0 || c.shape_layers < 0 || c.tok_layers < 0) bad("non-positive size");
+    if (c.n_max_faces < 1 || c.n_max_faces > c.tok_max_pos) bad("n_max_faces out of range");
+    if (c.num_latents + 1 + c.n_max_faces * 9 + 2 > c.max_positions) bad("max_positions too small for cond_length + 9*n_max_faces + 2");
+    if (c.max_batch < 1 || c.kv_splits < 1 || c.kv_splits > 256 || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
+}
+
+void build_engine(ma_engine* e) {
+    const ma_config& c = e->cfg;
+    e->L = build_layout(c);
+    pack_state_init(e->L, e->ps);
+    e->T = c.num_latents + 1; e->V = c.codebook_size + 3; e->maxnew = c.n_max_faces * 9 + 2; e->maxseq = e->T + e->maxnew;
+    e->nf = c.n_max_faces; e->S = e->T + e->nf;
+    e->bf16 = c.dtype == MA_DTYPE_BF16; e->kv_elem = e->bf16 ? 2 : 4;
+    HIP_CHECK(hipMalloc(&e->arena, e->L.bytes));
+    HIP_CHECK(hipMemset(e->arena, 0, e->L.bytes));
+    e->kv_plane = (size_t)c.heads * e->maxseq * 64 * e->kv_elem;
+    HIP_CHECK(hipMalloc(&e->kv, e->kv_plane * 2 * c.layers));
+    HIP_CHECK(hipMemset(e->kv, 0, e->kv_plane * 2 * c.layers));
+    const int H = c.hidden;
+    e->d_e = e->dmalloc<float>(H); e->d_q = e->dmalloc<float>(H); e->d_attn = e->dmalloc<float>(H);
+    e->d_ypre1 = e->dmalloc<float>(H); e->d_ypre2 = e->dmalloc<float>(H); e->d_h0 = e->dmalloc<float>(H); e->d_h1 = e->dmalloc<float>(H);
+    e->d_ffn = e->dmalloc<float>(c.ffn); e->d_logits = e->dmalloc<float>(e->V);
+    e->d_part = e->dmalloc<float>((size_t)c.kv_splits * c.heads * ATTN_PART_STRIDE);
+    e->n_parts = gemv_num_waves(e->V);
+    e->d_pval = e->dmalloc<float>(e->n_parts); e->d_pidx = e->dmalloc<int>(e->n_parts);
+    e->d_st = e->dmalloc<DecState>(1); e->d_tokens = e->dmalloc<long long>(e->maxnew);
+    HIP_CHECK(hipMemset(e->d_st, 0, sizeof(DecState)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_flag), 64));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), (size_t)e->maxnew * sizeof(long long)));
+    // dense workspace, one sample
+    const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S;
+    const size_t rows_small = std::max(T, S);                       // rows of the latent / token streams
+    const size_t wmax = std::max(std::max(W, H), Wt);
+    const size_t fmax = std::max(std::max(4 * W, c.ffn), c.tok_ffn);
+    e->w_feat = e->dmalloc<float>((size_t)N * 64);
+    e->w_data = e->dmalloc<float>((size_t)N * W); e->w_dataln = e->dmalloc<float>((size_t)N * W); e->w_kv = e->dmalloc<float>((size_t)N * 2 * W);
+    e->w_a = e->dmalloc<float>(rows_small * wmax); e->w_b = e->dmalloc<float>(rows_small * wmax); e->w_c = e->dmalloc<float>(rows_small * wmax);
+    e->w_x = e->dmalloc<float>(rows_small * wmax);
+    e->w_qkv = e->dmalloc<float>(rows_small * 3 * wmax); e->w_mlp = e->dmalloc<float>(rows_small * fmax);
+    e->w_lat = e->dmalloc<float>((size_t)T * W); e->w_cat = e->dmalloc<float>((size_t)T * 2 * W); e->w_mean = e->dmalloc<float>((size_t)T * c.embed_dim);
+    e->w_fein = e->dmalloc<float>((size_t)e->nf * 3 * c.codebook_dim); e->w_fe = e->dmalloc<float>((size_t)e->nf * Wt);
+    e->w_logit = e->dmalloc<float>((size_t)e->nf * 9 * c.discrete_num); e->w_mask = e->dmalloc<unsigned char>(e->nf);
+    const size_t B = c.max_batch;
+    e->w_latents = e->dmalloc<float>(B * T * W); e->w_prefix = e->dmalloc<float>(B * T * H);
+    e->w_tokens = e->dmalloc<long long>(B * e->maxnew); e->w_ids = e->dmalloc<long long>(B * (size_t)e->nf * 9);
+    // per-layer decode pointers
+    e->dl.resize(c.layers);
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = DEC + "layers." + std::to_string(l) + ".";
+        DecLayerPtrs& w = e->dl[l];
+        w.qkv_w = e->P(p + "qkv.weight"); w.qkv_b = e->PF(p + "qkv.bias");
+        w.o_w = e->P(p + "self_attn.out_proj.weight"); w.o_b = e->PF(p + "self_attn.out_proj.bias");
+        w.fc1_w = e->P(p + "fc1.weight"); w.fc1_b = e->PF(p + "fc1.bias");
+        w.fc2_w = e->P(p + "fc2.weight"); w.fc2_b = e->PF(p + "fc2.bias");
+        w.ln1_g = e->PF(p + "self_attn_layer_norm.weight"); w.ln1_b = e->PF(p + "self_attn_layer_norm.bias");
+        w.ln2_g = e->PF(p + "final_layer_norm.weight"); w.ln2_b = e->PF(p + "final_layer_norm.bias");
+    }
+}
+
+template <typename F>
+int guarded(ma_engine* e, F f) {
+    try {
+        if (e) { hipError_t r = hipSetDevice(e->device); if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(r)); }
+        f();
+        return MA_OK;
+    } catch (const MaError& x) {
+        if (e) e->err = x.msg; else g_create_error = x.msg;
+        return x.code;
+    } catch (const std::exception& x) {
+        if (e) e->err = x.what(); else g_create_error = x.what();
+        return MA_ERR_INVALID;
+    } catch (...) {
+        if (e) e->err = "unknown exception"; else g_create_error = "unknown exception";
+        return MA_ERR_INVALID;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* ma_version(void) { return "meshanything_amd 0.1 (gfx950)"; }
+
+const char* ma_last_error(const ma_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int ma_engine_create(ma_engine** out, const ma_config* cfg, int device) {
+    if (!out || !cfg) { g_create_error = "null argument"; return MA_ERR_INVALID; }
+    *out = nullptr;
+    ma_engine* e = nullptr;
+    int rc = guarded(nullptr, [&] {
+        validate_config(*cfg);
+        int ndev = 0;
+        HIP_CHECK(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) throw MaError(MA_ERR_INVALID, "device index out of range (" + std::to_string(ndev) + " visible)");
+        HIP_CHECK(hipSetDevice(device));
+        e = new ma_engine();
+        e->cfg = *cfg; e->device = device;
+        build_engine(e);
+    });
+    if (rc != MA_OK) { if (e) ma_engine_destroy(e); return rc; }
+    *out = e;
+    return MA_OK;
+}
+
+void ma_engine_destroy(ma_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->kv) (void)hipFree(e->kv);
+    if (e->h_flag) (void)hipHostFree(e->h_flag);
+    if (e->h_tokens) (void)hipHostFree(e->h_tokens);
+    delete e;
+}
+
+int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
+    if (!e || !name) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        const std::string n = name;
+        if (n == "gemm_impl") e->opt_gemm_impl = (int)value;
+        else if (n == "prefill_stepwise") e->opt_prefill_stepwise = (int)value;
+        else if (n == "use_graph") {
+            e->cfg.use_graph = (int)value;
+        } else throw MaError(MA_ERR_INVALID, "unknown option " + n);
+    });
+}
+
+int ma_engine_load_weights(ma_engine* e, const ma_tensor_desc* tensors, int n) {
+    if (!e || (!tensors && n > 0)) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        for (int i = 0; i < n; ++i) {
+            std::string err;
+            int rc = pack_tensor(e->L, e->ps, tensors[i], err, [&](size_t off, const void* p, size_t nb) {
+                HIP_CHECK(hipMemcpy(e->arena + off, p, nb, hipMemcpyHostToDevice));
+            });
+            if (rc != MA_OK) throw MaError(rc, err);
+        }
+    });
+}
+
+int ma_engine_finalize_weights(ma_engine* e) {
+    if (!e) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        std::string missing;
+        if (!pack_complete(e->L, e->ps, missing)) throw MaError(MA_ERR_MISSING, "checkpoint incomplete, missing: " + missing);
+        e->weights_ready = true;
+    });
+}
+
+int ma_engine_arena(ma_engine* e, void** dev_ptr, size_t* bytes) {
+    if (!e || !dev_ptr || !bytes) return MA_ERR_INVALID;
+    *dev_ptr = e->arena; *bytes = e->L.bytes;
+    return MA_OK;
+}
+
+int ma_engine_mark_weights_loaded(ma_engine* e) {
+    if (!e) return MA_ERR_INVALID;
+    e->weights_ready = true;
+    return MA_OK;
+}
+
+int ma_engine_broadcast_weights(ma_engine* e, void* nccl_comm, int root, void* stream) {
+    if (!e || !nccl_comm) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        // RCCL is resolved lazily so that the library loads on hosts without librccl (CPU-only checks)
+        typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+        static bcast_fn fn = nullptr;
+        if (!fn) {
+            void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) throw MaError(MA_ERR_NCCL, std::string("cannot load librccl.so: ") + dlerror());
+            fn = reinterpret_cast<bcast_fn>(dlsym(h, "ncclBroadcast"));
+            if (!fn) throw MaError(MA_ERR_NCCL, "ncclBroadcast not found in librccl.so");
+        }
+        const int rc = fn(e->arena, e->arena, e->L.bytes, /*ncclInt8*/ 0, root, nccl_comm, reinterpret_cast<hipStream_t>(stream));
+        if (rc != 0) throw MaError(MA_ERR_NCCL, "ncclBroadcast failed with code " + std::to_string(rc));
+        e->weights_ready = true;
+    });
+}
+
+// ---- host-only arena description / packing ------------------------------------------------------------------------
+static int layout_for(const ma_config* cfg, Layout& L, std::string& err) {
+    try { validate_config(*cfg); L = build_layout(*cfg); return MA_OK; }
+    catch (const MaError& x) { err = x.msg; return x.code; }
+    catch (const std::exception& x) { err = x.what(); return MA_ERR_INVALID; }
+}
+
+int64_t ma_arena_bytes(const ma_config* cfg) {
+    if (!cfg) return MA_ERR_INVALID;
+    Layout L; std::string err;
+    int rc = layout_for(cfg, L, err);
+    if (rc != MA_OK) { g_create_error = err; return rc; }
+    return (int64_t)L.bytes;
+}
+
+int ma_arena_num_entries(const ma_config* cfg) {
+    if (!cfg) return MA_ERR_INVALID;
+    Layout L; std::string err;
+    int rc = layout_for(cfg, L, err);
+    if (rc != MA_OK) { g_create_error = err; return rc; }
+    return (int)L.entries.size();
+}
+
+int ma_arena_entry(const ma_config* cfg, int i, char* name, int name_cap, int64_t* offset, int64_t* bytes, int32_t* dtype, int32_t* rows, int32_t* cols) {
+    if (!cfg) return MA_ERR_INVALID;
+    Layout L; std::string err;
+    int rc = layout_for(cfg, L, err);
+    if (rc != MA_OK) { g_create_error = err; return rc; }
+    if (i < 0 || i >= (int)L.entries.size()) return MA_ERR_INVALID;
+    const Entry& en = L.entries[i];
+    if (name && name_cap > 0) { snprintf(name, name_cap, "%s", en.name.c_str()); }
+    if (offset) *offset = (int64_t)en.offset;
+    if (bytes) *bytes = (int64_t)en.bytes;
+    if (dtype) *dtype = en.dtype;
+    if (rows) *rows = en.rows;
+    if (cols) *cols = en.cols;
+    return MA_OK;
+}
+
+int ma_pack_weights_host(const ma_config* cfg, const ma_tensor_desc* tensors, int n, void* host_arena, char* err, int err_cap) {
+    auto fail = [&](int code, const std::string& m) { if (err && err_cap > 0) snprintf(err, err_cap, "%s", m.c_str()); return code; };
+    if (!cfg || !host_arena || (!tensors && n > 0)) return fail(MA_ERR_INVALID, "null argument");
+    Layout L; std::string e;
+    int rc = layout_for(cfg, L, e);
+    if (rc != MA_OK) return fail(rc, e);
+    PackState ps; pack_state_init(L, ps);
+    std::memset(host_arena, 0, L.bytes);
+    for (int i = 0; i < n; ++i) {
+        rc = pack_tensor(L, ps, tensors[i], e, [&](size_t off, const void* p, size_t nb) { std::memcpy(reinterpret_cast<char*>(host_arena) + off, p, nb); });
+        if (rc != MA_OK) return fail(rc, e);
+    }
+    std::string missing;
+    if (!pack_complete(L, ps, missing)) return fail(MA_ERR_MISSING, "checkpoint incomplete, missing: " + missing);
+    return MA_OK;
+}
+
+int ma_engine_upload_arena(ma_engine* e, const void* host_arena, size_t bytes) {
+    if (!e || !host_arena) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        if (bytes != e->L.bytes) throw MaError(MA_ERR_SHAPE, "arena size mismatch");
+        HIP_CHECK(hipMemcpy(e->arena, host_arena, bytes, hipMemcpyHostToDevice));
+        e->weights_ready = true;
+    });
+}
+
+// ---- hot path ------------------------------------------------------------------------------------------------------
+int ma_encode(ma_engine* e, const void* pc, int pc_dtype, int B, float* latents, float* prefix, void* stream) {
+    if (!e || !pc || !latents) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        if (pc_dtype != MA_DTYPE_F32 && pc_dtype != MA_DTYPE_F16) throw MaError(MA_ERR_INVALID, "pc_dtype must be F32 or F16");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const size_t pstride = (size_t)e->cfg.n_points * 6 * (pc_dtype == MA_DTYPE_F16 ? 2 : 4);
+        for (int b = 0; b < B; ++b) {
+            float* lat = latents + (size_t)b * e->T * e->cfg.enc_width;
+            encode_one(e, s, reinterpret_cast<const char*>(pc) + b * pstride, pc_dtype, lat);
+            if (prefix) prefix_one(e, s, lat, prefix + (size_t)b * e->T * e->cfg.hidden);
+        }
+    });
+}
+
+int ma_generate(ma_engine* e, const float* prefix, int B, const ma_sample_cfg* sc_in, int64_t* tokens, int32_t* lengths, int32_t* n_generated, void* stream) {
+    if (!e || !prefix || !tokens) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const ma_sample_cfg sc = resolve_sample_cfg(e, sc_in);
+        int nmax = 0;
+        for (int b = 0; b < B; ++b) {
+            // rows are independent (no cross-batch op anywhere in meshanything.py:134-176): generated one after another in round 1
+            const int len = generate_one(e, s, prefix + (size_t)b * e->T * e->cfg.hidden, sc, b, reinterpret_cast<long long*>(tokens) + (size_t)b * e->maxnew);
+            if (lengths) lengths[b] = len;
+            nmax = std::max(nmax, len);
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (n_generated) *n_generated = nmax;
+    });
+}
+
+int ma_postprocess_tokens(ma_engine* e, const int64_t* tokens, int B, int n_generated, int64_t* ids, void* stream) {
+    if (!e || !tokens || !ids) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        check_batch(e, B);
+        if (n_generated < 0 || n_generated > e->maxnew) throw MaError(MA_ERR_INVALID, "n_generated out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const int total = B * (e->maxnew - 2);
+        hipLaunchKernelGGL(postprocess_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(tokens), e->maxnew,
+                           n_generated, e->maxnew, reinterpret_cast<long long*>(ids), B);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int ma_detokenize(ma_engine* e, const int64_t* ids, const float* latents, int B, float* coords, void* stream) {
+    if (!e || !ids || !latents || !coords) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        for (int b = 0; b < B; ++b)
+            detok_one(e, s, reinterpret_cast<const long long*>(ids) + (size_t)b * e->nf * 9, latents + (size_t)b * e->T * e->cfg.enc_width,
+                      coords + (size_t)b * e->nf * 9);
+    });
+}
+
+int ma_forward(ma_engine* e, const void* pc, int pc_dtype, int B, const ma_sample_cfg* sc, float* coords, int64_t* tokens, int32_t* lengths,
+               int32_t* n_generated, int64_t* ids, float* latents, void* stream) {
+    if (!e || !pc || !coords) return MA_ERR_INVALID;
+    int rc = guarded(e, [&] { require_ready(e); check_batch(e, B); });
+    if (rc != MA_OK) return rc;
+    float* lat = latents ? latents : e->w_latents;
+    int64_t* tok = tokens ? tokens : reinterpret_cast<int64_t*>(e->w_tokens);
+    int64_t* idp = ids ? ids : reinterpret_cast<int64_t*>(e->w_ids);
+    int32_t ngen = 0;
+    if ((rc = ma_encode(e, pc, pc_dtype, B, lat, e->w_prefix, stream)) != MA_OK) return rc;
+    if ((rc = ma_generate(e, e->w_prefix, B, sc, tok, lengths, &ngen, stream)) != MA_OK) return rc;
+    if (n_generated) *n_generated = ngen;
+    if ((rc = ma_postprocess_tokens(e, tok, B, ngen, idp, stream)) != MA_OK) return rc;
+    if ((rc = ma_detokenize(e, idp, lat, B, coords, stream)) != MA_OK) return rc;
+    return guarded(e, [&] { HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream))); });
+}
+
+// ---- kernel-level entry points -------------------------------------------------------------------------------------
+int ma_op_gemv(int wdtype, const void* W, const float* bias, const float* x, const float* ln_g, const float* ln_b, float ln_eps, const float* res,
+               float* y, float* xn_out, int N, int K, int act, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!W || !x || !y || N < 1 || K < 8 || K % 8) throw MaError(MA_ERR_INVALID, "ma_op_gemv: bad arguments");
+        GemvArgs a{};
+        a.W = W; a.bias = bias; a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.xn_out = xn_out; a.res = res; a.y = y; a.N = N; a.K = K;
+        a.act = act; a.round_x = wdtype == MA_DTYPE_BF16; a.epi = EPI_PLAIN;
+        if (wdtype == MA_DTYPE_BF16) gemv_launch<bf16_t>(a, reinterpret_cast<hipStream_t>(stream));
+        else if (wdtype == MA_DTYPE_F32) gemv_launch<float>(a, reinterpret_cast<hipStream_t>(stream));
+        else throw MaError(MA_ERR_INVALID, "ma_op_gemv: wdtype");
+    });
+}
+
+int ma_op_gemm(int wdtype, int impl, const float* A, int lda, const void* W, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+               int K, int act, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!A || !W || !C) throw MaError(MA_ERR_INVALID, "ma_op_gemm: null pointer");
+        GemmArgs g{A, lda, W, bias, R, ldr, C, ldc, M, N, K, act};
+        hipError_t r;
+        if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, impl, reinterpret_cast<hipStream_t>(stream));
+        else if (wdtype == MA_DTYPE_F32) r = launch_gemm<float>(g, impl, reinterpret_cast<hipStream_t>(stream));
+        else throw MaError(MA_ERR_INVALID, "ma_op_gemm: wdtype");
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("ma_op_gemm: ") + hipGetErrorString(r));
+    });
+}
+
+int ma_op_layernorm(const float* x, int ldx, const float* g, const float* b, float eps, float* y, int ldy, int rows, int D, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!x || !g || !b || !y) throw MaError(MA_ERR_INVALID, "ma_op_layernorm: null pointer");
+        hipLaunchKernelGGL(ln_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, g, b, eps, y, ldy, rows, D);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int ma_op_attention(const float* Q, int q_rs, int q_hs, const float* K, int k_rs, int k_hs, const float* V, int v_rs, int v_hs, float* O, int o_rs, int Sq,
+                    int Sk, int H, float scale, int causal_offset, int round_bf16, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!Q || !K || !V || !O) throw MaError(MA_ERR_INVALID, "ma_op_attention: null pointer");
+        AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, V, v_rs, v_hs, O, o_rs, Sq, Sk, H, scale, causal_offset, round_bf16};
+        HIP_CHECK(launch_attention(a, reinterpret_cast<hipStream_t>(stream)));
+    });
+}
+
+int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int splits, float* out,
+                           void* workspace, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!q || !kcache || !vcache || !out || !workspace || len < 1 || len > max_seq || splits < 1) throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: bad arguments");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        float* part = reinterpret_cast<float*>(workspace);
+        if (kvdtype == MA_DTYPE_BF16)
+            hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(splits, H), dim3(256), 0, s, q, reinterpret_cast<const bf16_t*>(kcache),
+                               reinterpret_cast<const bf16_t*>(vcache), max_seq, (const DecState*)nullptr, len, 1, part);
+        else if (kvdtype == MA_DTYPE_F32)
+            hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(splits, H), dim3(256), 0, s, q, reinterpret_cast<const float*>(kcache),
+                               reinterpret_cast<const float*>(vcache), max_seq, (const DecState*)nullptr, len, 0, part);
+        else throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: kvdtype");
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(H), dim3(64), 0, s, part, splits, out);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------------------
+int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out, void* stream) {
+    if (!e || !out) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e);
+        if (steps < 1 || steps > 64) throw MaError(MA_ERR_INVALID, "steps must be in [1,64]");
+        if (kv_len < e->T + 1 || kv_len + 3 * steps + 8 > e->maxseq) throw MaError(MA_ERR_INVALID, "kv_len out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        std::memset(out, 0, sizeof(*out));
+        ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
+        sc.suppress_eos = 1;
+        ensure_graph(e, s);
+        auto reset = [&] {
+            init_state(e, s, sc, 0, e->maxnew);
+            // state as if t tokens had been generated and the cache held kv_len-1 rows
+            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5);
+            HIP_CHECK(hipGetLastError());
+        };
+        // (a) per-launch event brackets, eager
+        reset();
+        std::vector<hipEvent_t> ev; std::vector<int> cls;
+        StepTimer tm; tm.ev = &ev; tm.cls = &cls; tm.s = s;
+        for (int i = 0; i < steps; ++i) enqueue_decode_step(e, s, -1, tm);
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < cls.size(); ++i) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            out->launches[cls[i]] += 1; out->ms[cls[i]] += ms;
+        }
+        for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+        // (b) whole-step times: eager launches and graph replays, events around `steps` steps
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        StepTimer none;
+        reset();
+        HIP_CHECK(hipEventRecord(a, s));
+        for (int i = 0; i < steps; ++i) enqueue_decode_step(e, s, -1, none);
+        HIP_CHECK(hipEventRecord(b, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        out->step_ms_eager = ms / steps;
+        if (e->gexec) {
+            reset();
+            HIP_CHECK(hipEventRecord(a, s));
+            for (int i = 0; i < steps; ++i) HIP_CHECK(hipGraphLaunch(e->gexec, s));
+            HIP_CHECK(hipEventRecord(b, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+            out->step_ms_graph = ms / steps;
+        }
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// Small row-wise / gather / sampling kernels around the GEMMs.  Each cites the reference lines it implements.
+#pragma once
+#include "common.hpp"
+#include "state.hpp"
+
+namespace ma {
+
+constexpr int TOK_BOS = 0, TOK_EOS = 1, TOK_PAD = 2;      // meshanything.py:102-104
+
+// FourierEmbedder.forward (embedder.py:87-105, logspace, include_pi=False, include_input=True) + normals concat
+// (sal_perceiver.py:87-89): out[i] = [x(3) | sin(x_d * 2^f) (d-major) | cos(...) | normal(3) | 0-pad to ld]
+template <typename PT>
+__global__ void fourier_kernel(const PT* __restrict__ pc, int n_points, int F, float* __restrict__ out, int ld) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_points * ld) return;
+    const int i = idx / ld, col = idx - i * ld;
+    const PT* p = pc + (size_t)i * 6;
+    float v = 0.f;
+    if (col < 3) v = (float)p[col];
+    else if (col < 3 + 6 * F) {
+        const int j = (col - 3) % (3 * F);
+        const int dim = j / F, fr = j - dim * F;
+        const float arg = (float)p[dim] * (float)(1 << fr);
+        v = (col < 3 + 3 * F) ? sinf(arg) : cosf(arg);
+    } else if (col < 6 + 6 * F) v = (float)p[3 + col - (3 + 6 * F)];
+    out[idx] = v;
+}
+
+// nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32).  y may alias x.
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                      const float* __restrict__ b, float eps, float* __restrict__ y, int ldy,
+                                                      int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    float* yr = y + (size_t)row * ldy;
+    for (int k = lane; k < D; k += 64) yr[k] = (xr[k] - mean) * rstd * g[k] + b[k];
+}
+
+// out[i][n] = (mask == null || mask[i] ? in[i][n] : 0) + (t0 ? t0[n] : 0) + (tab ? tab[(i + row0) * ld_tab + n] : 0)
+//  - decoder prefill: prefix + cond_embed[0] + embed_positions[2 + i]         (shape_opt.py:331-337, 359-364)
+//  - detokenizer:     point feature + point_pe[i]; masked face embeds + pos_embedding[i]   (meshanything.py:47, 58-60)
+__global__ void add_rows_kernel(const float* __restrict__ in, int ld_in, const unsigned char* __restrict__ mask,
+                                const float* __restrict__ t0, const float* __restrict__ tab, int ld_tab, int row0,
+                                float* __restrict__ out, int ld_out, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    float v = (mask == nullptr || mask[i]) ? in[(size_t)i * ld_in + n] : 0.f;
+    if (t0) v += t0[n];
+    if (tab) v += tab[(size_t)(i + row0) * ld_tab + n];
+    out[(size_t)i * ld_out + n] = v;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    dst[(size_t)i * ldd + n] = src[(size_t)i * lds + n];
+}
+
+__global__ void zero_masked_rows_kernel(float* __restrict__ x, int ld, const unsigned char* __restrict__ mask, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    if (!mask[i]) x[(size_t)i * ld + n] = 0.f;
+}
+
+// meshanything.py:141-142,163-172: eos-pad the generated tokens to 9F+2, drop first and last, specials -> -1, others -= 3
+__global__ void postprocess_tokens_kernel(const long long* __restrict__ tokens, int ld_tokens, int n_generated, int max_new,
+                                          long long* __restrict__ ids, int B) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = max_new - 2;
+    if (idx >= B * L) return;
+    const int b = idx / L, j = idx - b * L;
+    const int src = j + 1;                                      // outputs[:, 1:-1]
+    long long t = src < n_generated ? tokens[(size_t)b * ld_tokens + src] : (long long)TOK_EOS;
+    ids[idx] = (t == TOK_BOS || t == TOK_EOS || t == TOK_PAD) ? -1 : t - 3;
+}
+
+// get_codes (meshanything.py:178-212) fused with the 'b (nf nv) d -> b nf (nv d)' rearrange (:53) and the face mask (:57):
+// out[f][v*D + d] = sum_{q<3} codebook[ids[f*9 + v*3 + q]][d] (pad -1 contributes 0); mask[f] = all nine ids != -1
+__global__ void codes_gather_kernel(const long long* __restrict__ ids, const float* __restrict__ codebook, int D, int nf,
+                                    float* __restrict__ out, unsigned char* __restrict__ mask) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nf * 3 * D) return;
+    const int f = idx / (3 * D), rem = idx - f * 3 * D, v = rem / D, d = rem - v * D;
+    const long long* ip = ids + (size_t)f * 9 + v * 3;
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const long long id = ip[q]; c[q] = id < 0 ? 0.f : codebook[(size_t)id * D + d]; }
+    out[idx] = (c[0] + c[1]) + c[2];
+    if (rem == 0) {
+        bool ok = true;
+        for (int q = 0; q < 9; ++q) ok = ok && ids[(size_t)f * 9 + q] != -1;
+        mask[f] = ok ? 1 : 0;
+    }
+}
+
+// meshanything.py:69-78 + undiscretize (214-223): argmax over the discrete bins (lowest index wins ties),
+// coord = idx / num_discrete * (0.5 - -0.5) + -0.5, NaN for masked faces.  One wave per (face, coordinate).
+__global__ __launch_bounds__(256) void coords_argmax_kernel(const float* __restrict__ logits, int nf, int nd,
+                                                            const unsigned char* __restrict__ mask, float* __restrict__ coords) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= nf * 9) return;
+    const float* lp = logits + (size_t)item * nd;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int k = lane; k < nd; k += 64) { const float v = lp[k]; if (arg_better(v, k, bv, bi)) { bv = v; bi = k; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const int f = item / 9;
+        float t = (float)bi;
+        t = t / (float)nd;
+        t = t * (0.5f - (-0.5f)) + (-0.5f);
+        coords[item] = mask[f] ? t : __builtin_nanf("");
+    }
+}
+
+// ---- token pick: greedy argmax or top-k -> top-p -> inverse-CDF draw ([3p] GenerationMixin greedy / sample with
+// TopKLogitsWarper + TopPLogitsWarper, call site meshanything.py:143-162), plus the generate() bookkeeping:
+// a finished row emits pad, eos marks the row finished, the token becomes next step's input.
+__device__ inline float hash_uniform(unsigned long long seed, int row, int t) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(((unsigned long long)row << 32) | (unsigned)t);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+constexpr int PICK_KMAX = 64;
+
+__global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ logits, int V, const float* __restrict__ part_val,
+                                                   const int* __restrict__ part_idx, int nparts, DecState* st,
+                                                   long long* __restrict__ tokens_out, int T) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];      // V floats (sampling only)
+    __shared__ float rv[4]; __shared__ int ri[4];
+    __shared__ float cv[PICK_KMAX]; __shared__ int ci[PICK_KMAX];
+    __shared__ int chosen;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int do_sample = st->do_sample;
+    if (!do_sample) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 4; ++i) if (arg_better(rv[i], ri[i], bv, bi)) { bv = rv[i]; bi = ri[i]; }
+            chosen = bi;
+        }
+    } else {
+        const int k = min(min(st->top_k, V), PICK_KMAX);
+        for (int i = tid; i < V; i += 256) dyn[i] = (st->suppress_eos && i == TOK_EOS) ? -INFINITY : logits[i];
+        __syncthreads();
+        for (int round = 0; round < k; ++round) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int i = tid; i < V; i += 256) { const float v = dyn[i]; if (arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int i = 1; i < 4; ++i) if (arg_better(rv[i], ri[i], bv, bi)) { bv = rv[i]; bi = ri[i]; }
+                cv[round] = bv; ci[round] = bi;
+                if (bi < V) dyn[bi] = -INFINITY;      // selected: removed from later rounds (also if bv == -inf)
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            // candidates are in descending order.  top-p: drop the ascending prefix whose cumulative mass <= 1 - top_p
+            float e[PICK_KMAX];
+            float sum = 0.f;
+            for (int j = 0; j < k; ++j) { e[j] = expf(cv[j] - cv[0]); sum += e[j]; }
+            const float thr = (float)(1.0 - (double)st->top_p);
+            int keep = k;
+            float cum = 0.f;
+            for (int j = k - 1; j >= 1; --j) { cum += e[j] / sum; if (cum <= thr) keep = j; else break; }
+            float sum2 = 0.f;
+            for (int j = 0; j < keep; ++j) sum2 += e[j];
+            const int t = st->t;
+            const float u = st->uniforms ? st->uniforms[t] : hash_uniform(st->seed, st->row, t);
+            int pick = keep - 1;
+            float acc = 0.f;
+            for (int j = 0; j < keep; ++j) { acc += e[j] / sum2; if (acc > u) { pick = j; break; } }
+            chosen = ci[pick];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int t = st->t;
+        int tok = chosen;
+        if (st->finished) tok = TOK_PAD;
+        if (t < st->max_new) tokens_out[t] = tok;
+        if (tok == TOK_EOS) st->finished = 1;
+        st->cur_tok = tok;
+        st->t = t + 1;
+        st->pos = T + t;          // next step feeds token t at cache row cond_length + (t+1) - 1
+    }
+}
+
+__global__ void init_state_kernel(DecState* st, DecState v) { *st = v; }
+// used by stepwise prefill / profiling: set the fields one decode step reads
+__global__ void set_pos_kernel(DecState* st, int t, int pos, int cur_tok) { st->t = t; st->pos = pos; st->cur_tok = cur_tok; }
+__global__ void fill_tokens_kernel(long long* p, long long v, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) p[idx] = v;
+}
+
+}  // namespace ma

@@ -1,0 +1,23 @@
+// Device-resident decode state: everything a captured decode step needs that changes from step to step lives
+// here (not in kernel arguments), so one hipGraph of the step can be replayed for the whole generation.
+#pragma once
+#include <stdint.h>
+
+namespace ma {
+
+struct DecState {
+    int t;             // tokens generated so far; the step being run produces token index t
+    int pos;           // KV-cache row of the token fed this step (= cond_length + t - 1; rows < cond_length = prefix)
+    int cur_tok;       // token fed this step (= token t-1)
+    int finished;      // this row has emitted eos (it keeps stepping and emits pad, like generate())
+    int suppress_eos;  // never pick eos
+    int do_sample;     // 0 greedy, 1 top-k/top-p/multinomial
+    int top_k;
+    float top_p;
+    unsigned long long seed;
+    const float* uniforms;   // (max_new_tokens) uniforms of this row, or null -> hashed from seed
+    int row;                 // batch row (decorrelates the hashed uniform stream)
+    int max_new;
+};
+
+}  // namespace ma

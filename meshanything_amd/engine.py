@@ -1,0 +1,214 @@
+"""Python handle on the HIP engine.  torch is used for device memory and streams only (plumbing): every
+computation below happens inside libmeshanything_amd.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import MAConfig, DTYPE_BF16, DTYPE_F32
+
+
+def _stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _ArenaView:
+    """Exposes the engine's device weight arena through __cuda_array_interface__ so torch can alias it."""
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class Engine:
+    def __init__(self, cfg: MAConfig, device: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("meshanything_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self._c = cfg.to_c()
+        h = C.c_void_p()
+        _lib.check(self.lib.ma_engine_create(C.byref(h), C.byref(self._c), device))
+        self.h = h
+        self._keep = []
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.ma_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        _lib.check(rc, self.h)
+
+    def set_option(self, name: str, value: int) -> None:
+        self._check(self.lib.ma_engine_set_option(self.h, name.encode(), int(value)))
+
+    # ---------------------------------------------------------------- weights (main.py:99-104)
+    @staticmethod
+    def _desc(name: str, arr) -> Tuple[_lib.TensorDesc, object]:
+        if isinstance(arr, torch.Tensor):
+            t = arr.detach().cpu().contiguous()
+            if t.dtype == torch.bfloat16:
+                a, dt = t.view(torch.int16).numpy(), _lib.DT_BF16
+            elif t.dtype == torch.float16:
+                a, dt = t.numpy(), _lib.DT_F16
+            else:
+                a, dt = t.float().numpy(), _lib.DT_F32
+        else:
+            a = np.ascontiguousarray(arr)
+            if a.dtype == np.float16:
+                dt = _lib.DT_F16
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                dt = _lib.DT_F32
+        shape = tuple(arr.shape)
+        d = _lib.TensorDesc()
+        d.name = name.encode()
+        d.dtype = dt
+        d.ndim = len(shape)
+        for i, s in enumerate(shape):
+            d.shape[i] = s
+        d.data = a.ctypes.data
+        return d, a
+
+    def load_weights(self, items: Iterable[Tuple[str, object]], finalize: bool = True) -> None:
+        """items: (reference state-dict key, ndarray | torch tensor).  Streams tensor by tensor (2.4 GB fp32 checkpoint)."""
+        for name, arr in items:
+            d, keep = self._desc(name, arr)
+            self._check(self.lib.ma_engine_load_weights(self.h, C.byref(d), 1))
+            del keep
+        if finalize:
+            self._check(self.lib.ma_engine_finalize_weights(self.h))
+
+    def arena_tensor(self) -> torch.Tensor:
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.ma_engine_arena(self.h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_ArenaView(p.value, n.value), device=self.device)
+
+    def mark_weights_loaded(self) -> None:
+        self._check(self.lib.ma_engine_mark_weights_loaded(self.h))
+
+    def upload_arena(self, host: np.ndarray) -> None:
+        self._check(self.lib.ma_engine_upload_arena(self.h, C.c_void_p(host.ctypes.data), host.nbytes))
+
+    # ---------------------------------------------------------------- hot path
+    def encode(self, pc_normal: torch.Tensor, want_prefix: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        cfg = self.cfg
+        assert pc_normal.dim() == 3 and pc_normal.shape[1] == cfg.n_points and pc_normal.shape[2] == 6, pc_normal.shape
+        x = pc_normal.to(self.device)
+        if x.dtype == torch.float16:
+            dt = _lib.DT_F16
+        else:
+            x, dt = x.float(), _lib.DT_F32
+        x = x.contiguous()
+        B = x.shape[0]
+        latents = torch.empty(B, cfg.cond_length, cfg.enc_width, dtype=torch.float32, device=self.device)
+        prefix = torch.empty(B, cfg.cond_length, cfg.hidden, dtype=torch.float32, device=self.device) if want_prefix else None
+        self._check(self.lib.ma_encode(self.h, _ptr(x), dt, B, _ptr(latents), _ptr(prefix), _stream_ptr()))
+        return latents, prefix
+
+    def _sample_cfg(self, sampling: bool, max_new_tokens: Optional[int], suppress_eos: bool, uniforms: Optional[torch.Tensor],
+                    seed: int, check_every: int, top_k: int, top_p: float) -> Tuple[_lib.SampleCfg, object]:
+        sc = _lib.SampleCfg()
+        sc.struct_size = C.sizeof(_lib.SampleCfg)
+        sc.do_sample = 1 if sampling else 0
+        sc.top_k, sc.top_p = top_k, top_p
+        sc.max_new_tokens = int(max_new_tokens or 0)
+        sc.suppress_eos = 1 if suppress_eos else 0
+        sc.check_every = check_every
+        sc.seed = seed
+        keep = None
+        if uniforms is not None:
+            keep = uniforms.to(self.device, torch.float32).contiguous()
+            sc.uniforms = keep.data_ptr()
+        return sc, keep
+
+    def generate(self, prefix: torch.Tensor, sampling: bool = False, max_new_tokens: Optional[int] = None,
+                 suppress_eos: bool = False, uniforms: Optional[torch.Tensor] = None, seed: int = 0, check_every: int = 64,
+                 top_k: int = 50, top_p: float = 0.95) -> Tuple[torch.Tensor, np.ndarray]:
+        """transformer.generate(inputs_embeds=prefix, ...) (meshanything.py:143-162) -> (tokens (B, n_generated), lengths)."""
+        cfg = self.cfg
+        prefix = prefix.to(self.device, torch.float32).contiguous()
+        B = prefix.shape[0]
+        maxn = int(max_new_tokens or cfg.max_new_tokens)
+        if uniforms is not None:
+            assert tuple(uniforms.shape) == (B, maxn), (uniforms.shape, (B, maxn))
+        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p)
+        tokens = torch.empty(B, cfg.max_new_tokens, dtype=torch.int64, device=self.device)
+        lengths = (C.c_int32 * B)()
+        ngen = C.c_int32()
+        self._check(self.lib.ma_generate(self.h, _ptr(prefix), B, C.byref(sc), _ptr(tokens), lengths, C.byref(ngen), _stream_ptr()))
+        del keep
+        return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32)
+
+    def postprocess_tokens(self, results: torch.Tensor) -> torch.Tensor:
+        """meshanything.py:163-172.  results (B, n<=max_new) -> ids (B, 9*n_max_faces)."""
+        cfg = self.cfg
+        B, n = results.shape
+        full = torch.full((B, cfg.max_new_tokens), 2, dtype=torch.int64, device=self.device)
+        full[:, :n] = results.to(self.device)
+        ids = torch.empty(B, cfg.n_max_faces * 9, dtype=torch.int64, device=self.device)
+        self._check(self.lib.ma_postprocess_tokens(self.h, _ptr(full), B, n, _ptr(ids), _stream_ptr()))
+        return ids
+
+    def detokenize(self, ids: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+        """tokenizer(ids, get_codes(ids), point_feature=latents) (meshanything.py:173-174) -> (B, F, 3, 3)."""
+        cfg = self.cfg
+        ids = ids.to(self.device, torch.int64).contiguous()
+        latents = latents.to(self.device, torch.float32).contiguous()
+        B = ids.shape[0]
+        coords = torch.empty(B, cfg.n_max_faces, 3, 3, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ma_detokenize(self.h, _ptr(ids), _ptr(latents), B, _ptr(coords), _stream_ptr()))
+        return coords
+
+    def forward(self, pc_normal: torch.Tensor, sampling: bool = False, max_new_tokens: Optional[int] = None,
+                suppress_eos: bool = False, uniforms: Optional[torch.Tensor] = None, seed: int = 0, check_every: int = 64,
+                top_k: int = 50, top_p: float = 0.95) -> Dict[str, object]:
+        """MeshAnything.forward (meshanything.py:134-176) in one library call."""
+        cfg = self.cfg
+        x = pc_normal.to(self.device)
+        if x.dtype == torch.float16:
+            dt = _lib.DT_F16
+        else:
+            x, dt = x.float(), _lib.DT_F32
+        x = x.contiguous()
+        B = x.shape[0]
+        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p)
+        coords = torch.empty(B, cfg.n_max_faces, 3, 3, dtype=torch.float32, device=self.device)
+        tokens = torch.empty(B, cfg.max_new_tokens, dtype=torch.int64, device=self.device)
+        ids = torch.empty(B, cfg.n_max_faces * 9, dtype=torch.int64, device=self.device)
+        latents = torch.empty(B, cfg.cond_length, cfg.enc_width, dtype=torch.float32, device=self.device)
+        lengths = (C.c_int32 * B)()
+        ngen = C.c_int32()
+        self._check(self.lib.ma_forward(self.h, _ptr(x), dt, B, C.byref(sc), _ptr(coords), _ptr(tokens), lengths, C.byref(ngen),
+                                        _ptr(ids), _ptr(latents), _stream_ptr()))
+        del keep
+        return {"coords": coords, "tokens": tokens[:, :ngen.value], "lengths": np.array(list(lengths), dtype=np.int32),
+                "ids": ids, "latents": latents}
+
+    # ---------------------------------------------------------------- measurement
+    def profile_decode(self, kv_len: int, steps: int = 4) -> Dict[str, object]:
+        kt = _lib.KernelTiming()
+        self._check(self.lib.ma_profile_decode(self.h, kv_len, steps, C.byref(kt), _stream_ptr()))
+        names = ["gemv", "attn_decode", "attn_combine", "pick"]
+        return {"launches": {n: kt.launches[i] for i, n in enumerate(names)}, "ms": {n: kt.ms[i] for i, n in enumerate(names)},
+                "step_ms_graph": kt.step_ms_graph, "step_ms_eager": kt.step_ms_eager, "steps": steps, "kv_len": kv_len}
+
+
+def build_engine(cfg: MAConfig, items: Iterable[Tuple[str, object]], device: int = 0) -> Engine:
+    eng = Engine(cfg, device)
+    eng.load_weights(items)
+    return eng

@@ -476,3 +476,34 @@ def verify_greedy_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Ten
     gaps = (srt[:, 0] - srt[:, 1])
     return {"n": n, "ambiguous": len(diff) - len(hard), "hard": hard, "worst_margin": max(margins) if margins else 0.0,
             "median_top_gap": float(gaps.median()), "min_top_gap": float(gaps.min())}
+
+
+def verify_sampled_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Tensor, uniforms: np.ndarray, tol: float = 1e-4,
+                          suppress_eos: bool = False) -> Dict[str, object]:
+    """Teacher-forced check of a top-k/top-p sampled stream drawn with injected uniforms: at every step the
+    oracle's own filtered distribution must put `tokens[j]` on the CDF interval that contains uniforms[j]
+    (within `tol`: two implementations differ by fp32 summation order in the logits)."""
+    logits = oracle.teacher_forced_logits(prefix, tokens)
+    n = tokens.shape[0]
+    exact, ambiguous, hard = 0, 0, []
+    for j in range(n):
+        lg = logits[j].clone()
+        if suppress_eos:
+            lg[EOS] = float("-inf")
+        kept, probs = Oracle.topk_topp_filter(lg)
+        pick = Oracle.sample_from(kept, probs, float(uniforms[j]))
+        tok = int(tokens[j])
+        if pick == tok:
+            exact += 1
+            continue
+        kl = kept.tolist()
+        ok = False
+        if tok in kl:
+            c = np.concatenate([[0.0], np.cumsum(probs.double().numpy())])
+            i = kl.index(tok)
+            ok = (c[i] - tol) <= float(uniforms[j]) <= (c[i + 1] + tol)
+        if ok:
+            ambiguous += 1
+        else:
+            hard.append((j, tok, pick))
+    return {"n": n, "exact": exact, "ambiguous": ambiguous, "hard": hard}

@@ -1,0 +1,186 @@
+"""Kernel-level parity (MI355X): each HIP kernel, called through the C ABI (ma_op_*), against a plain PyTorch fp32
+reference of the same op with the same rounding points."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from meshanything_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return _lib.load()
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(lib, rc):
+    from meshanything_amd import _lib
+    _lib.check(rc, None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _relerr(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / max(1e-6, float(ref.abs().max())))
+
+
+@pytest.mark.parametrize("wdtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096), (8195, 1024), (128, 128), (256, 128), (67, 256), (128, 2048)])
+@pytest.mark.parametrize("variant", ["plain", "ln_relu_res"])
+def test_gemv(lib, wdtype, N, K, variant):
+    g = torch.Generator().manual_seed(N * 7 + K + wdtype)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    x = torch.randn(K, generator=g) * 1.5 + 0.3
+    bias = torch.randn(N, generator=g) * 0.1
+    ln = variant == "ln_relu_res"
+    lg = 1 + 0.1 * torch.randn(K, generator=g)
+    lb = 0.05 * torch.randn(K, generator=g)
+    res = torch.randn(N, generator=g)
+    # reference
+    xr = torch.nn.functional.layer_norm(x, (K,), lg, lb, 1e-5) if ln else x
+    Wr = _bf(W) if wdtype == 1 else W
+    xin = _bf(xr) if wdtype == 1 else xr
+    ref = (Wr.double() @ xin.double()).float() + bias
+    if ln:
+        ref = torch.relu(ref) + res
+    dev = "cuda"
+    Wd = (W.to(torch.bfloat16) if wdtype == 1 else W).to(dev).contiguous()
+    y = torch.full((N,), float("nan"), device=dev)
+    xn = torch.full((K,), float("nan"), device=dev)
+    xd, bd, lgd, lbd, rd = x.to(dev), bias.to(dev), lg.to(dev), lb.to(dev), res.to(dev)
+    _chk(lib, lib.ma_op_gemv(wdtype, _p(Wd), _p(bd), _p(xd), _p(lgd) if ln else None, _p(lbd) if ln else None, 1e-5,
+                             _p(rd) if ln else None, _p(y), _p(xn) if ln else None, N, K, 1 if ln else 0, _stream()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any()
+    assert _relerr(y, ref) < 2e-5, _relerr(y, ref)
+    if ln:
+        assert _relerr(xn, xr) < 1e-5
+
+
+@pytest.mark.parametrize("wdtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("impl", [0, 1], ids=["mfma", "valu"])
+@pytest.mark.parametrize("M,N,K,act,use_res", [(257, 768, 768, 0, True), (4096, 768, 64, 0, False), (257, 2304, 768, 0, False),
+                                               (1057, 3072, 768, 2, False), (17, 128, 128, 1, True), (1, 1024, 768, 0, False),
+                                               (100, 96, 32, 0, False), (256, 64, 3072, 0, True)])
+def test_gemm(lib, wdtype, impl, M, N, K, act, use_res):
+    g = torch.Generator().manual_seed(M + 3 * N + 5 * K + wdtype)
+    # asymmetric data so that a transposed fragment layout cannot pass
+    A = torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5
+    W = torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02
+    bias = torch.randn(N, generator=g) * 0.1
+    R = torch.randn(M, N, generator=g)
+    Ar, Wr = (_bf(A), _bf(W)) if wdtype == 1 else (A, W)
+    ref = (Ar.double() @ Wr.double().t()).float() + bias
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if use_res:
+        ref = ref + R
+    dev = "cuda"
+    Ad = A.to(dev).contiguous()
+    Wd = (W.to(torch.bfloat16) if wdtype == 1 else W).to(dev).contiguous()
+    Cd = torch.full((M, N), float("nan"), device=dev)
+    bd, Rd = bias.to(dev), R.to(dev).contiguous()
+    _chk(lib, lib.ma_op_gemm(wdtype, impl, _p(Ad), K, _p(Wd), _p(bd), _p(Rd) if use_res else None, N, _p(Cd), N, M, N, K, act, _stream()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(Cd).any()
+    assert _relerr(Cd, ref) < 3e-5, _relerr(Cd, ref)
+
+
+def test_layernorm(lib):
+    g = torch.Generator().manual_seed(3)
+    for rows, D, eps in ((257, 768, 1e-5), (1057, 768, 1e-12), (5, 1024, 1e-5), (17, 128, 1e-5)):
+        x = torch.randn(rows, D, generator=g) * 3 + 1
+        gm, bt = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+        ref = torch.nn.functional.layer_norm(x, (D,), gm, bt, eps)
+        xd, y = x.cuda(), torch.empty(rows, D, device="cuda")
+        _chk(lib, lib.ma_op_layernorm(_p(xd), D, _p(gm.cuda()), _p(bt.cuda()), eps, _p(y), D, rows, D, _stream()))
+        torch.cuda.synchronize()
+        assert float((y.cpu() - ref).abs().max()) < 2e-5
+
+
+def _attn_ref(q, k, v, scale, causal_offset, rnd):
+    # q (Sq,H,64) k,v (Sk,H,64)
+    if rnd:
+        q, k, v = _bf(q), _bf(k), _bf(v)
+    w = torch.einsum("qhd,khd->hqk", q.double(), k.double()) * scale
+    if causal_offset >= 0:
+        Sq, Sk = q.shape[0], k.shape[0]
+        mask = torch.arange(Sk)[None, :] > (torch.arange(Sq)[:, None] + causal_offset)
+        w = w.masked_fill(mask[None], float("-inf"))
+    p = torch.softmax(w, dim=-1)
+    return torch.einsum("hqk,khd->qhd", p, v.double()).float().reshape(q.shape[0], -1)
+
+
+@pytest.mark.parametrize("rnd", [0, 1], ids=["f32", "bf16in"])
+@pytest.mark.parametrize("Sq,Sk,H,layout,causal", [(257, 4096, 12, "cross", -1), (257, 257, 12, "interleaved", -1), (257, 257, 16, "std", 0),
+                                                    (1057, 1057, 12, "std", -1), (17, 17, 2, "std", 0), (70, 130, 2, "std", 60)])
+def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
+    g = torch.Generator().manual_seed(Sq + Sk + H)
+    q = torch.randn(Sq, H, 64, generator=g)
+    k = torch.randn(Sk, H, 64, generator=g)
+    v = torch.randn(Sk, H, 64, generator=g)
+    ref = _attn_ref(q, k, v, 0.125, causal, rnd)
+    dev = "cuda"
+    if layout == "std":          # q | k | v blocks of H*64 (OPT / BERT fused projection)
+        assert Sq == Sk or True
+        Qb = q.reshape(Sq, H * 64).to(dev).contiguous()
+        Kb = k.reshape(Sk, H * 64).to(dev).contiguous()
+        Vb = v.reshape(Sk, H * 64).to(dev).contiguous()
+        args = (Qb, H * 64, 64, Kb, H * 64, 64, Vb, H * 64, 64)
+        ptrs = (_p(Qb), H * 64, 64, _p(Kb), H * 64, 64, _p(Vb), H * 64, 64)
+    elif layout == "interleaved":  # per head [q|k|v] (transformer_blocks.py:61-62)
+        buf = torch.cat([q, k, v], dim=-1).reshape(Sq, H * 192).to(dev).contiguous()
+        base = buf.data_ptr()
+        ptrs = (C.c_void_p(base), H * 192, 192, C.c_void_p(base + 64 * 4), H * 192, 192, C.c_void_p(base + 128 * 4), H * 192, 192)
+        args = (buf,)
+    else:                        # cross: q (Sq, H*64); kv per head [k|v] (transformer_blocks.py:172-174)
+        Qb = q.reshape(Sq, H * 64).to(dev).contiguous()
+        kv = torch.cat([k, v], dim=-1).reshape(Sk, H * 128).to(dev).contiguous()
+        base = kv.data_ptr()
+        ptrs = (_p(Qb), H * 64, 64, C.c_void_p(base), H * 128, 128, C.c_void_p(base + 64 * 4), H * 128, 128)
+        args = (Qb, kv)
+    O = torch.full((Sq, H * 64), float("nan"), device=dev)
+    _chk(lib, lib.ma_op_attention(*ptrs, _p(O), H * 64, Sq, Sk, H, 0.125, causal, rnd, _stream()))
+    torch.cuda.synchronize()
+    del args
+    assert not torch.isnan(O).any()
+    assert float((O.cpu() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("kvdtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("length,splits", [(1, 16), (5, 16), (257, 16), (300, 4), (1000, 7), (7459, 16), (7459, 32)])
+def test_decode_attention(lib, kvdtype, length, splits):
+    H, max_seq = 16, 7459
+    g = torch.Generator().manual_seed(length + splits)
+    q = torch.randn(H * 64, generator=g)
+    k = torch.randn(H, max_seq, 64, generator=g)
+    v = torch.randn(H, max_seq, 64, generator=g)
+    rnd = kvdtype == 1
+    kk, vv = k[:, :length].permute(1, 0, 2), v[:, :length].permute(1, 0, 2)
+    ref = _attn_ref(q.reshape(1, H, 64), kk, vv, 0.125, -1, rnd)[0]
+    dev = "cuda"
+    kd = (k.to(torch.bfloat16) if rnd else k).to(dev).contiguous()
+    vd = (v.to(torch.bfloat16) if rnd else v).to(dev).contiguous()
+    out = torch.full((H * 64,), float("nan"), device=dev)
+    ws = torch.empty(splits * H * 66, device=dev)
+    _chk(lib, lib.ma_op_decode_attention(kvdtype, _p(q.to(dev)), _p(kd), _p(vd), H, max_seq, length, splits, _p(out), _p(ws), _stream()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
