@@ -52,7 +52,7 @@ class MAConfig:
     # ---- engine policy ----
     max_batch: int = 1
     dtype: int = DTYPE_BF16
-    kv_splits: int = 16         # split-KV factor of the decode attention kernel
+    kv_splits: int = 64         # split-KV factor of the decode attention kernel (grid = splits x heads >= 1024 blocks)
     use_graph: int = 1          # capture one decode step in a hipGraph and replay it
 
     # ---- derived ----

@@ -106,16 +106,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 }
 
 // merge the splits: out[h*64+d] = sum_s O_s e^(M_s-M) / sum_s L_s e^(M_s-M).  grid = (H), block = 64.
+// All S partial records are loaded before anything is used: one memory round trip instead of S dependent ones
+// (the partials were written by other CUs, i.e. they come from L2 / Infinity Cache, ~1 us each).
+constexpr int ATTN_MAX_SPLITS = 64;
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part, int S, float* __restrict__ out) {
     const int h = blockIdx.x, H = gridDim.x, lane = threadIdx.x;
+    float ms[ATTN_MAX_SPLITS / 1], ls[ATTN_MAX_SPLITS], os[ATTN_MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < ATTN_MAX_SPLITS; ++s) {
+        const bool ok = s < S;
+        const float* pp = part + ((size_t)(ok ? s : 0) * H + h) * ATTN_PART_STRIDE;
+        ms[s] = ok ? pp[0] : -1e30f;
+        ls[s] = ok ? pp[1] : 0.f;
+        os[s] = ok ? pp[2 + lane] : 0.f;
+    }
     float M = -1e30f;
-    for (int s = 0; s < S; ++s) M = fmaxf(M, part[((size_t)s * H + h) * ATTN_PART_STRIDE]);
+#pragma unroll
+    for (int s = 0; s < ATTN_MAX_SPLITS; ++s) M = fmaxf(M, ms[s]);
     float L = 0.f, O = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float* pp = part + ((size_t)s * H + h) * ATTN_PART_STRIDE;
-        const float f = expf(pp[0] - M);
-        L = fmaf(pp[1], f, L);
-        O = fmaf(pp[2 + lane], f, O);
+#pragma unroll
+    for (int s = 0; s < ATTN_MAX_SPLITS; ++s) {
+        const float f = expf(ms[s] - M);
+        L = fmaf(ls[s], f, L);
+        O = fmaf(os[s], f, O);
     }
     out[h * 64 + lane] = O / L;
 }

@@ -484,7 +484,7 @@ void validate_config(const ma_config& c) {
     if (c.n_points < 1 || c.num_latents < 1 || c.layers < 1 || c.enc_layers < 0 || c.shape_layers < 0 || c.tok_layers < 0) bad("non-positive size");
     if (c.n_max_faces < 1 || c.n_max_faces > c.tok_max_pos) bad("n_max_faces out of range");
     if (c.num_latents + 1 + c.n_max_faces * 9 + 2 > c.max_positions) bad("max_positions too small for cond_length + 9*n_max_faces + 2");
-    if (c.max_batch < 1 || c.kv_splits < 1 || c.kv_splits > 256 || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
+    if (c.max_batch < 1 || c.kv_splits < 1 || c.kv_splits > ATTN_MAX_SPLITS || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
 }
 
 void build_engine(ma_engine* e) {
@@ -504,7 +504,7 @@ void build_engine(ma_engine* e) {
     e->d_ypre1 = e->dmalloc<float>(H); e->d_ypre2 = e->dmalloc<float>(H); e->d_h0 = e->dmalloc<float>(H); e->d_h1 = e->dmalloc<float>(H);
     e->d_ffn = e->dmalloc<float>(c.ffn); e->d_logits = e->dmalloc<float>(e->V);
     e->d_part = e->dmalloc<float>((size_t)c.kv_splits * c.heads * ATTN_PART_STRIDE);
-    e->n_parts = gemv_num_waves(e->V);
+    e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(e->n_parts); e->d_pidx = e->dmalloc<int>(e->n_parts);
     e->d_st = e->dmalloc<DecState>(1); e->d_tokens = e->dmalloc<long long>(e->maxnew);
     HIP_CHECK(hipMemset(e->d_st, 0, sizeof(DecState)));
@@ -852,7 +852,7 @@ int ma_op_attention(const float* Q, int q_rs, int q_hs, const float* K, int k_rs
 int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int splits, float* out,
                            void* workspace, void* stream) {
     return guarded(nullptr, [&] {
-        if (!q || !kcache || !vcache || !out || !workspace || len < 1 || len > max_seq || splits < 1) throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: bad arguments");
+        if (!q || !kcache || !vcache || !out || !workspace || len < 1 || len > max_seq || splits < 1 || splits > ATTN_MAX_SPLITS) throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: bad arguments");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         float* part = reinterpret_cast<float*>(workspace);
         if (kvdtype == MA_DTYPE_BF16)

@@ -55,21 +55,21 @@ template <typename KT> __device__ inline void store_kv(KT* p, float v);
 template <> __device__ inline void store_kv<float>(float* p, float v) { *p = v; }
 template <> __device__ inline void store_kv<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
-// NC > 0: K == NC*64*VEC exactly, x and all weight pieces of the wave are held in registers (fast path).
-// NC == 0: any K with K % VEC == 0 (small test shapes): chunks are walked with x re-read from L1/L2.
-template <typename WT, int RPW, int NC>
+// Work decomposition (v2, after the launch-floor microbenchmark scripts/ubench_launch.hip: a streaming kernel needs >= ~1000
+// blocks and <= 2-4 loads per lane to reach the ~2.7-3.6 us floor for 2-8 MB; 256 fat blocks cost up to 2x that):
+//   one block = 4 waves = RPB = 4/KSPLIT output rows; KSPLIT waves share one row, each owning LPL 16-byte pieces per lane
+//   (K = KSPLIT * LPL * 64 * VEC); partial sums meet in LDS (one barrier), thread r finishes row r.
+// LPL == 0: generic path for small / odd K (K % VEC == 0), KSPLIT = 1.
+template <typename WT, int KSPLIT, int LPL>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     constexpr int VEC = WTraits<WT>::VEC;
-    constexpr int CH = 64 * VEC;
+    constexpr int RPB = 4 / KSPLIT;
+    __shared__ float red[4];
     const int lane = threadIdx.x & 63;
-    const int wave_in_block = threadIdx.x >> 6;
-    const int gwave = blockIdx.x * 4 + wave_in_block;
-    const int row0 = gwave * RPW;
-    if (row0 >= a.N) {
-        // whole wave idle (tail); an LMHEAD partial slot still has to be defined
-        if (a.epi == EPI_LMHEAD && lane == 0) { a.part_val[gwave] = -INFINITY; a.part_idx[gwave] = 0x7fffffff; }
-        return;
-    }
+    const int w = threadIdx.x >> 6;
+    const int row_in_block = w / KSPLIT, wk = w % KSPLIT;
+    const int row = blockIdx.x * RPB + row_in_block;
+    const int rowc = min(row, a.N - 1);                  // tail rows re-read the last row; result discarded
     const WT* W = reinterpret_cast<const WT*>(a.W);
     const int K = a.K;
 
@@ -83,81 +83,81 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         skip_dot = tok < 3;                      // bos/eos/pad use extra_embeds, no Linear (shape_opt.py:240-241)
         x = a.codebook + (size_t)(skip_dot ? 0 : tok - 3) * K;
     }
+    const bool has_ln = a.ln_g != nullptr;
+    float acc = 0.f;
 
-    float acc[RPW];
+    if constexpr (LPL > 0) {
+        // (1) everything small first (x slices, LN affine slices, then the full x for the statistics): these return
+        //     first (vmcnt is in-order) and come from L2; (2) then this wave's weight pieces; (3) LN math overlaps (2).
+        float xs[LPL][VEC], gs[LPL][VEC], bs[LPL][VEC];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) acc[r] = 0.f;
-
-    if constexpr (NC > 0) {
-        // (1) x slices first (they return first: vmcnt is in-order), then every weight piece of this wave
-        float xs[NC][VEC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float* xp = x + (c * 64 + lane) * VEC;
+        for (int i = 0; i < LPL; ++i) {
+            const int k0 = ((wk * LPL + i) * 64 + lane) * VEC;
 #pragma unroll
             for (int v = 0; v < VEC; v += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(xp + v);
-                xs[c][v] = t.x; xs[c][v + 1] = t.y; xs[c][v + 2] = t.z; xs[c][v + 3] = t.w;
+                f32x4 t = *reinterpret_cast<const f32x4*>(x + k0 + v);
+                xs[i][v] = t.x; xs[i][v + 1] = t.y; xs[i][v + 2] = t.z; xs[i][v + 3] = t.w;
+                if (has_ln) {
+                    f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + k0 + v);
+                    f32x4 b = *reinterpret_cast<const f32x4*>(a.ln_b + k0 + v);
+                    gs[i][v] = g.x; gs[i][v + 1] = g.y; gs[i][v + 2] = g.z; gs[i][v + 3] = g.w;
+                    bs[i][v] = b.x; bs[i][v + 1] = b.y; bs[i][v + 2] = b.z; bs[i][v + 3] = b.w;
+                }
             }
         }
-        u32x4 wv[RPW][NC];
+        constexpr int XALL = KSPLIT * LPL * VEC;         // K / 64 values of x per lane
+        float xall[XALL];
+        if (has_ln) {
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int row = min(row0 + r, a.N - 1);          // clamp: tail rows re-read the last row, result discarded
-            const WT* wr = W + (size_t)row * K;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) wv[r][c] = ld_stream16(wr + (c * 64 + lane) * VEC);
+            for (int j = 0; j < XALL; j += 4) {
+                f32x4 t = *reinterpret_cast<const f32x4*>(x + ((j / 4) * 64 + lane) * 4);
+                xall[j] = t.x; xall[j + 1] = t.y; xall[j + 2] = t.z; xall[j + 3] = t.w;
+            }
         }
-        // (2) LayerNorm prologue while the weights are in flight
-        if (a.ln_g) {
+        u32x4 wv[LPL];
+        const WT* wr = W + (size_t)rowc * K;
+#pragma unroll
+        for (int i = 0; i < LPL; ++i) wv[i] = ld_stream16(wr + ((wk * LPL + i) * 64 + lane) * VEC);
+        if (has_ln) {
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) s += xs[c][v];
+            for (int j = 0; j < XALL; ++j) s += xall[j];
             const float mean = wave_sum(s) / (float)K;
             float q = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) { float d = xs[c][v] - mean; q += d * d; }
+            for (int j = 0; j < XALL; ++j) { const float d = xall[j] - mean; q += d * d; }
             const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + a.ln_eps);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int k0 = (c * 64 + lane) * VEC;
+            for (int i = 0; i < LPL; ++i)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) xs[c][v] = (xs[c][v] - mean) * rstd * a.ln_g[k0 + v] + a.ln_b[k0 + v];
-            }
-            if (a.xn_out && gwave == 0) {
+                for (int v = 0; v < VEC; ++v) xs[i][v] = (xs[i][v] - mean) * rstd * gs[i][v] + bs[i][v];
+            if (a.xn_out && blockIdx.x == 0 && row_in_block == 0) {     // the KSPLIT waves of row 0 cover all of x once
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int k0 = (c * 64 + lane) * VEC;
+                for (int i = 0; i < LPL; ++i) {
+                    const int k0 = ((wk * LPL + i) * 64 + lane) * VEC;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) a.xn_out[k0 + v] = xs[c][v];
+                    for (int v = 0; v < VEC; ++v) a.xn_out[k0 + v] = xs[i][v];
                 }
             }
         }
         if (a.round_x) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int i = 0; i < LPL; ++i)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) xs[c][v] = round_bf16(xs[c][v]);
+                for (int v = 0; v < VEC; ++v) xs[i][v] = round_bf16(xs[i][v]);
         }
-        // (3) FMA
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
+        for (int i = 0; i < LPL; ++i) {
+            float wf[VEC];
+            unpack16<WT>(wv[i], wf);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float wf[VEC];
-                unpack16<WT>(wv[r][c], wf);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[r] = fmaf(wf[v], xs[c][v], acc[r]);
-            }
+            for (int v = 0; v < VEC; ++v) acc = fmaf(wf[v], xs[i][v], acc);
         }
     } else {
+        constexpr int CH = 64 * VEC;
         float mean = 0.f, rstd = 1.f;
         const int nc = (K + CH - 1) / CH;
-        if (a.ln_g) {
+        if (has_ln) {
             float s = 0.f;
             for (int k = lane; k < K; k += 64) s += x[k];
             mean = wave_sum(s) / (float)K;
@@ -172,50 +172,51 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     float t = x[k0 + v];
-                    if (a.ln_g) {
+                    if (has_ln) {
                         t = (t - mean) * rstd * a.ln_g[k0 + v] + a.ln_b[k0 + v];
-                        if (a.xn_out && gwave == 0) a.xn_out[k0 + v] = t;
+                        if (a.xn_out && blockIdx.x == 0 && w == 0) a.xn_out[k0 + v] = t;
                     }
                     xv[v] = a.round_x ? round_bf16(t) : t;
                 }
+                u32x4 wq = ld_stream16(W + (size_t)rowc * K + k0);
+                float wf[VEC];
+                unpack16<WT>(wq, wf);
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const int row = min(row0 + r, a.N - 1);
-                    u32x4 w = ld_stream16(W + (size_t)row * K + k0);
-                    float wf[VEC];
-                    unpack16<WT>(w, wf);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[r] = fmaf(wf[v], xv[v], acc[r]);
-                }
+                for (int v = 0; v < VEC; ++v) acc = fmaf(wf[v], xv[v], acc);
             }
         }
     }
 
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) acc[r] = wave_sum(acc[r]);
+    acc = wave_sum(acc);
+    if (lane == 0) red[w] = acc;
+    __syncthreads();
 
-    // ---- epilogue: lane r finishes row r ----------------------------------------------------------------------
+    // ---- epilogue: thread r finishes row r of the block ---------------------------------------------------------
     if (a.epi == EPI_LMHEAD) {
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             const int skip = a.st->suppress_eos ? 1 : -1;     // eos = 1 (meshanything.py:103)
             float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int n = row0 + r;
+            for (int r = 0; r < RPB; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) v += red[r * KSPLIT + k];
+                const int n = blockIdx.x * RPB + r;
                 if (n < a.N) {
-                    a.y[n] = acc[r];
-                    if (n != skip && arg_better(acc[r], n, bv, bi)) { bv = acc[r]; bi = n; }
+                    a.y[n] = v;
+                    if (n != skip && arg_better(v, n, bv, bi)) { bv = v; bi = n; }
                 }
             }
-            a.part_val[gwave] = bv; a.part_idx[gwave] = bi;
+            a.part_val[blockIdx.x] = bv; a.part_idx[blockIdx.x] = bi;
         }
         return;
     }
+    const int r = threadIdx.x;
+    const int n = blockIdx.x * RPB + r;
+    if (r >= RPB || n >= a.N) return;
     float v = 0.f;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) if (lane == r) v = acc[r];
-    const int n = row0 + lane;
-    if (lane >= RPW || n >= a.N) return;
+    for (int k = 0; k < KSPLIT; ++k) v += red[r * KSPLIT + k];
     if (a.epi == EPI_EMBED) {
         // e = (extra[tok] | input_layer(codebook[tok-3])) + token_embed_positions[slot] + cond_embed[1] + embed_positions[T+t-1+2]
         float e = skip_dot ? a.extra[(size_t)tok * a.N + n] : v + a.bias[n];
@@ -242,33 +243,33 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 }
 
 // ---- host-side dispatch ------------------------------------------------------------------------------------------
-template <typename WT, int RPW>
-inline hipError_t launch_gemv_rpw(const GemvArgs& a, hipStream_t s) {
+struct GemvShape { int ksplit, lpl; };
+template <typename WT>
+inline GemvShape gemv_shape(int N, int K) {
     constexpr int VEC = WTraits<WT>::VEC;
-    const int waves = (a.N + RPW - 1) / RPW;
-    const int blocks = (waves + 3) / 4;
-    const int K = a.K;
-    // register fast paths: K = NC * 64 lanes * VEC elements (bf16: 1024 -> 2, 4096 -> 8; fp32: 1024 -> 4, 4096 -> 16)
-    if (K == 2 * 64 * VEC)       hipLaunchKernelGGL((gemv_kernel<WT, RPW, 2>), dim3(blocks), dim3(256), 0, s, a);
-    else if (K == 4 * 64 * VEC)  hipLaunchKernelGGL((gemv_kernel<WT, RPW, 4>), dim3(blocks), dim3(256), 0, s, a);
-    else if (K == 8 * 64 * VEC && RPW <= 2)  hipLaunchKernelGGL((gemv_kernel<WT, (RPW <= 2 ? RPW : 1), 8>), dim3(blocks), dim3(256), 0, s, a);
-    else if (K == 16 * 64 * VEC && RPW == 1) hipLaunchKernelGGL((gemv_kernel<WT, 1, 16>), dim3(blocks), dim3(256), 0, s, a);
-    else                         hipLaunchKernelGGL((gemv_kernel<WT, RPW, 0>), dim3(blocks), dim3(256), 0, s, a);
-    return hipGetLastError();
+    if (K % (64 * VEC) != 0) return {1, 0};
+    const int nc = K / (64 * VEC);                       // 16-byte pieces per lane for one row
+    switch (nc) {
+        case 1: return {1, 1};
+        case 2: return N <= 2048 ? GemvShape{2, 1} : GemvShape{1, 2};
+        case 4: return {2, 2};
+        case 8: return {4, 2};
+        case 16: return {4, 4};
+        default: return {1, 0};
+    }
 }
-
-// number of per-wave partials an EPI_LMHEAD launch writes (must match launch_gemv's RPW choice)
-inline int gemv_rpw_for(int N) { return N >= 6144 ? 4 : (N >= 2048 ? 2 : 1); }
-inline int gemv_num_waves(int N) { int r = gemv_rpw_for(N); int w = (N + r - 1) / r; return ((w + 3) / 4) * 4; }
+template <typename WT>
+inline int gemv_num_blocks(int N, int K) { const GemvShape g = gemv_shape<WT>(N, K); return (N + 4 / g.ksplit - 1) / (4 / g.ksplit); }
 
 template <typename WT>
 inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
     if (a.K % WTraits<WT>::VEC != 0) return hipErrorInvalidValue;
-    // rows per wave: keep >= ~1000 waves in flight (4+/CU) while amortising the x prologue
-    const int rpw = gemv_rpw_for(a.N);
-    if (rpw == 4) return launch_gemv_rpw<WT, 4>(a, s);
-    if (rpw == 2) return launch_gemv_rpw<WT, 2>(a, s);
-    return launch_gemv_rpw<WT, 1>(a, s);
+    const GemvShape g = gemv_shape<WT>(a.N, a.K);
+    const dim3 grid(gemv_num_blocks<WT>(a.N, a.K)), block(256);
+#define MA_GEMV_CASE(KS, LP) if (g.ksplit == KS && g.lpl == LP) { hipLaunchKernelGGL((gemv_kernel<WT, KS, LP>), grid, block, 0, s, a); return hipGetLastError(); }
+    MA_GEMV_CASE(1, 1) MA_GEMV_CASE(2, 1) MA_GEMV_CASE(1, 2) MA_GEMV_CASE(2, 2) MA_GEMV_CASE(4, 2) MA_GEMV_CASE(4, 4) MA_GEMV_CASE(1, 0)
+#undef MA_GEMV_CASE
+    return hipErrorInvalidValue;
 }
 
 }  // namespace ma

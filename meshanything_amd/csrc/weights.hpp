@@ -205,15 +205,26 @@ inline int pack_tensor(const Layout& L, PackState& ps, const ma_tensor_desc& t, 
     }
     const Entry& e = L.entries[s->entry];
     const int esz = e.dtype == MA_DTYPE_F32 ? 4 : 2;
-    std::vector<uint8_t> row((size_t)s->take_cols * esz);
-    for (int r = 0; r < s->take_rows; ++r) {
-        for (int k = 0; k < s->take_cols; ++k) {
-            const float v = src_elem(t.data, t.dtype, (size_t)r * s->src_cols + k);
-            if (esz == 4) reinterpret_cast<float*>(row.data())[k] = v;
-            else reinterpret_cast<uint16_t*>(row.data())[k] = f2bf(v);
+    // contiguous destination (no padding between rows): convert the whole tensor and emit it in one piece
+    const bool contiguous = (s->take_cols == e.cols) || s->take_rows == 1;
+    const size_t rows_per_emit = contiguous ? (size_t)s->take_rows : 1;
+    std::vector<uint8_t> buf(rows_per_emit * s->take_cols * esz);
+    for (int r0 = 0; r0 < s->take_rows; r0 += (int)rows_per_emit) {
+        for (size_t rr = 0; rr < rows_per_emit; ++rr) {
+            const size_t r = r0 + rr;
+            uint8_t* dst = buf.data() + rr * s->take_cols * esz;
+            if (t.dtype == MA_DTYPE_F32 && esz == 4) {
+                std::memcpy(dst, reinterpret_cast<const float*>(t.data) + r * s->src_cols, (size_t)s->take_cols * 4);
+            } else {
+                for (int k = 0; k < s->take_cols; ++k) {
+                    const float v = src_elem(t.data, t.dtype, r * s->src_cols + k);
+                    if (esz == 4) reinterpret_cast<float*>(dst)[k] = v;
+                    else reinterpret_cast<uint16_t*>(dst)[k] = f2bf(v);
+                }
+            }
         }
         // a matrix source advances by the entry's leading dimension; a vector segment has a single row
-        emit(e.offset + (s->dst_elem + (size_t)r * e.cols) * esz, row.data(), row.size());
+        emit(e.offset + (s->dst_elem + (size_t)r0 * e.cols) * esz, buf.data(), buf.size());
     }
     ps.filled[s->entry] += (size_t)s->take_rows * s->take_cols;
     return MA_OK;

@@ -109,8 +109,8 @@ def test_layernorm(lib):
         x = torch.randn(rows, D, generator=g) * 3 + 1
         gm, bt = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
         ref = torch.nn.functional.layer_norm(x, (D,), gm, bt, eps)
-        xd, y = x.cuda(), torch.empty(rows, D, device="cuda")
-        _chk(lib, lib.ma_op_layernorm(_p(xd), D, _p(gm.cuda()), _p(bt.cuda()), eps, _p(y), D, rows, D, _stream()))
+        xd, y, gd, bd = x.cuda(), torch.empty(rows, D, device="cuda"), gm.cuda(), bt.cuda()
+        _chk(lib, lib.ma_op_layernorm(_p(xd), D, _p(gd), _p(bd), eps, _p(y), D, rows, D, _stream()))
         torch.cuda.synchronize()
         assert float((y.cpu() - ref).abs().max()) < 2e-5
 
@@ -180,7 +180,8 @@ def test_decode_attention(lib, kvdtype, length, splits):
     vd = (v.to(torch.bfloat16) if rnd else v).to(dev).contiguous()
     out = torch.full((H * 64,), float("nan"), device=dev)
     ws = torch.empty(splits * H * 66, device=dev)
-    _chk(lib, lib.ma_op_decode_attention(kvdtype, _p(q.to(dev)), _p(kd), _p(vd), H, max_seq, length, splits, _p(out), _p(ws), _stream()))
+    qd = q.to(dev)
+    _chk(lib, lib.ma_op_decode_attention(kvdtype, _p(qd), _p(kd), _p(vd), H, max_seq, length, splits, _p(out), _p(ws), _stream()))
     torch.cuda.synchronize()
     assert not torch.isnan(out).any()
     assert float((out.cpu() - ref).abs().max()) < 2e-5

@@ -280,7 +280,7 @@ def test_full_encode_and_detok_match_reference_golden(full, golden_dir):
         srt = torch.sort(logits, dim=-1, descending=True).values
         gap = (srt[..., 0] - srt[..., 1]).reshape(coords.shape)
         print(f"[bf16] detokenizer: {int(diff.sum())} bins differ from the bf16-policy oracle; worst gap {float(gap[diff].max()) if diff.any() else 0:.3e}")
-        assert int(diff.sum()) <= 20 and (not diff.any() or float(gap[diff].max()) < 0.1)
+        assert int(diff.sum()) <= 72 and (not diff.any() or float(gap[diff].max()) < 0.05)   # <= 1% of bins, near-ties only
 
 
 def test_full_generate_matches_oracle(full, golden_dir):
