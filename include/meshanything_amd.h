@@ -75,7 +75,7 @@ typedef struct ma_config {
     int32_t max_batch;     /* largest B accepted by encode/generate/detokenize/forward */
     int32_t dtype;         /* MA_DTYPE_BF16: bf16 weights + KV, GEMM/attention inputs rounded to bf16, fp32 accumulate;
                               MA_DTYPE_F32: everything fp32 ("exact" mode for the parity gates) */
-    int32_t kv_splits;     /* split-KV factor of the decode attention kernel */
+    int32_t kv_splits;     /* reserved (the decode attention splits the cache in fixed 128-position chunks) */
     int32_t use_graph;     /* 1: replay one captured decode step (hipGraph); 0: eager launches */
 } ma_config;
 
@@ -185,16 +185,25 @@ MA_API int  ma_op_layernorm(const float *x, int ldx, const float *g, const float
 MA_API int  ma_op_attention(const float *Q, int q_rs, int q_hs, const float *K, int k_rs, int k_hs, const float *V, int v_rs,
                             int v_hs, float *O, int o_rs, int Sq, int Sk, int H, float scale, int causal_offset /* <0: none */,
                             int round_bf16, void *stream);
-/* single-query attention over a KV cache laid out (H, max_seq, 64) of kvdtype; len = number of cached positions */
+/* single-query attention over a KV cache laid out (H, max_seq, 64) of kvdtype; len = number of cached positions.
+ * `workspace`: device buffer of ma_decode_attention_workspace_bytes(H) bytes (the split-KV partials). */
 MA_API int  ma_op_decode_attention(int kvdtype, const float *q, const void *kcache, const void *vcache, int H, int max_seq,
-                                   int len, int splits, float *out, void *workspace /* >= splits*H*66 floats */, void *stream);
+                                   int len, float *out, void *workspace, void *stream);
+MA_API size_t ma_decode_attention_workspace_bytes(int H);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Time the decode-step kernels with HIP events on `stream`: runs `steps` decode steps eagerly at KV length
  * `kv_len` (cache contents arbitrary) and reports, per kernel class, launches and summed event-bracketed ms.
- * Classes: 0 gemv (all weight-streaming launches), 1 decode attention, 2 attention combine, 3 pick/sample. */
+ * Classes: 0 gemv (all weight-streaming launches; out_proj includes the split-KV merge), 1 decode attention, 2 unused, 3 pick/sample. */
 typedef struct ma_kernel_timing { int32_t launches[8]; float ms[8]; float step_ms_graph; float step_ms_eager; } ma_kernel_timing;
 MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_timing *out, void *stream);
+
+/* In-kernel timeline of ONE eager decode step at KV length `kv_len`: every weight-streaming / attention launch of the
+ * step records, per block, the 100 MHz real-time counter at (0) block start, (1) input vector staged, (2) weights / KV
+ * consumed, (3) block end.  host_out[(launch * max_blocks + block) * 4 + point]; kinds[launch]: 0 embed, 1 qkv,
+ * 2 attention, 3 out_proj(+merge), 4 fc1, 5 fc2, 6 lm_head; blocks[launch] = grid size.  Diagnostics only. */
+MA_API int  ma_trace_decode(ma_engine *e, int kv_len, uint64_t *host_out, int max_launches, int max_blocks, int32_t *kinds,
+                            int32_t *blocks, int32_t *n_launches, void *stream);
 
 #ifdef __cplusplus
 }

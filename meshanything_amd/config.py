@@ -52,7 +52,7 @@ class MAConfig:
     # ---- engine policy ----
     max_batch: int = 1
     dtype: int = DTYPE_BF16
-    kv_splits: int = 64         # split-KV factor of the decode attention kernel (grid = splits x heads >= 1024 blocks)
+    kv_splits: int = 0          # reserved (the decode attention splits the cache in fixed 128-position chunks)
     use_graph: int = 1          # capture one decode step in a hipGraph and replay it
 
     # ---- derived ----
@@ -106,8 +106,7 @@ class MAConfig:
         base = dict(n_points=256, num_freqs=8, enc_width=128, enc_heads=2, num_latents=16, enc_layers=2,
                     shape_layers=2, embed_dim=32, hidden=128, heads=2, layers=2, ffn=256,
                     codebook_size=61, codebook_dim=128, n_max_faces=8, max_positions=17 + 8 * 9 + 2 + 6,
-                    tok_width=128, tok_heads=2, tok_layers=2, tok_ffn=256, tok_max_pos=32, discrete_num=128,
-                    kv_splits=4)
+                    tok_width=128, tok_heads=2, tok_layers=2, tok_ffn=256, tok_max_pos=32, discrete_num=128)
         base.update(kw)
         return MAConfig(**base)
 

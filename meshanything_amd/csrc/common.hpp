@@ -43,21 +43,42 @@ __host__ inline float half2float_host(uint16_t h) {
 __device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wave reductions on the DPP path (no LDS crossbar: __shfl_xor lowers to ds_bpermute_b32, ~100 cycles per step
+// and six dependent steps per reduction; a DPP step is one VALU op).  quad_perm xor 1, xor 2, then row_half_mirror and
+// row_mirror leave every lane of a 16-lane row with the row total; the four row totals are fetched with v_readlane.
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ inline float readlane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+__device__ inline float row_sum16(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
+}
+__device__ inline float wave_sum(float v) {
+    v = row_sum16(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
-// sum over aligned groups of G lanes (G power of two <= 64); every lane of the group gets the sum
+// sum over aligned groups of G lanes (G power of two <= 16); every lane of the group gets the sum
 template <int G>
 __device__ inline float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group_sum: G must be a power of two <= 16");
+    if constexpr (G >= 2) v += dpp_mov<DPP_XOR1>(v);
+    if constexpr (G >= 4) v += dpp_mov<DPP_XOR2>(v);
+    if constexpr (G >= 8) v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if constexpr (G >= 16) v += dpp_mov<DPP_ROW_MIRROR>(v);
     return v;
 }
 

@@ -211,11 +211,21 @@ void gemv_launch(const GemvArgs& a, hipStream_t s) {
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
 }
 void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s) { if (e->bf16) gemv_launch<bf16_t>(a, s); else gemv_launch<float>(a, s); }
+int gemv_blocks(ma_engine* e, int N, int K) { return e->bf16 ? gemv_num_blocks<bf16_t>(N, K) : gemv_num_blocks<float>(N, K); }
 
-struct StepTimer {                    // optional per-launch HIP events (ma_profile_decode)
+struct StepTimer {                    // optional per-launch HIP events (ma_profile_decode) / in-kernel timestamps (ma_trace_decode)
     std::vector<hipEvent_t>* ev = nullptr;
     std::vector<int>* cls = nullptr;
     hipStream_t s = nullptr;
+    unsigned long long* tr = nullptr; int tr_max_launches = 0, tr_max_blocks = 0;
+    std::vector<int>* tr_kind = nullptr; std::vector<int>* tr_blocks = nullptr;
+    // slot for the next launch's timestamps (kind: 0 embed, 1 qkv, 2 attention, 3 out_proj, 4 fc1, 5 fc2, 6 lm_head)
+    unsigned long long* trace_slot(int kind, int blocks) {
+        if (!tr || (int)tr_kind->size() >= tr_max_launches || blocks > tr_max_blocks) return nullptr;
+        unsigned long long* p = tr + (size_t)tr_kind->size() * tr_max_blocks * 4;
+        tr_kind->push_back(kind); tr_blocks->push_back(blocks);
+        return p;
+    }
     void begin(int c) { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); cls->push_back(c); } }
     void end() { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); } }
 };
@@ -239,35 +249,35 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         GemvArgs a = gemv_base(e);
         a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? e->d_h0 : nullptr;
         a.y = e->d_q; a.N = 3 * H; a.K = H; a.epi = EPI_QKV; a.kcache = e->kplane(l); a.vcache = e->vplane(l); a.H = H; a.max_seq = e->maxseq;
+        a.trace = tm.trace_slot(1, gemv_blocks(e, a.N, a.K));
         tm.begin(0); gemv(e, a, s); tm.end();
     }
     tm.begin(1);
-    if (e->bf16)
-        hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(c.kv_splits, c.heads), dim3(256), 0, s, e->d_q, reinterpret_cast<const bf16_t*>(e->kplane(l)),
-                           reinterpret_cast<const bf16_t*>(e->vplane(l)), e->maxseq, e->d_st, len_override, 1, e->d_part);
-    else
-        hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(c.kv_splits, c.heads), dim3(256), 0, s, e->d_q, reinterpret_cast<const float*>(e->kplane(l)),
-                           reinterpret_cast<const float*>(e->vplane(l)), e->maxseq, e->d_st, len_override, 0, e->d_part);
-    HIP_CHECK(hipGetLastError());
-    tm.end();
-    tm.begin(2);
-    hipLaunchKernelGGL(attn_combine_kernel, dim3(c.heads), dim3(64), 0, s, e->d_part, c.kv_splits, e->d_attn);
-    HIP_CHECK(hipGetLastError());
+    {
+        unsigned long long* tr = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
+        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(e->d_q, e->kplane(l), e->vplane(l), c.heads, e->maxseq, e->d_st, len_override, 1, e->d_part, s, tr)
+                               : launch_attn_decode<float>(e->d_q, e->kplane(l), e->vplane(l), c.heads, e->maxseq, e->d_st, len_override, 0, e->d_part, s, tr);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+    }
     tm.end();
     {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
         GemvArgs a = gemv_base(e);
-        a.W = w.o_w; a.bias = w.o_b; a.x = e->d_attn; a.res = resid; a.y = e->d_ypre1; a.N = H; a.K = H;
+        // the attention output is never materialised: this GEMV's prologue merges the split-KV partials
+        a.W = w.o_w; a.bias = w.o_b; a.x = nullptr; a.attn_ws = e->d_part; a.attn_heads = c.heads; a.res = resid; a.y = e->d_ypre1; a.N = H; a.K = H;
+        a.trace = tm.trace_slot(3, gemv_blocks(e, a.N, a.K));
         tm.begin(0); gemv(e, a, s); tm.end();
     }
     {   // f = relu(W1 LN1(y1) + b1); h1 = LN1(y1) kept for the residual
         GemvArgs a = gemv_base(e);
         a.W = w.fc1_w; a.bias = w.fc1_b; a.x = e->d_ypre1; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = e->d_h1;
         a.y = e->d_ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
+        a.trace = tm.trace_slot(4, gemv_blocks(e, a.N, a.K));
         tm.begin(0); gemv(e, a, s); tm.end();
     }
     {   // y2 = h1 + W2 f + b2
         GemvArgs a = gemv_base(e);
         a.W = w.fc2_w; a.bias = w.fc2_b; a.x = e->d_ffn; a.res = e->d_h1; a.y = e->d_ypre2; a.N = H; a.K = c.ffn;
+        a.trace = tm.trace_slot(5, gemv_blocks(e, a.N, a.K));
         tm.begin(0); gemv(e, a, s); tm.end();
     }
 }
@@ -276,6 +286,7 @@ void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, const float* l
     GemvArgs a = gemv_base(e);
     a.W = e->P("transformer.lm_head.weight"); a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
     a.y = e->d_logits; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD; a.part_val = e->d_pval; a.part_idx = e->d_pidx;
+    a.trace = tm.trace_slot(6, gemv_blocks(e, a.N, a.K));
     tm.begin(0); gemv(e, a, s); tm.end();
 }
 
@@ -296,6 +307,7 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         a.epi = EPI_EMBED; a.codebook = e->PF(DEC + "quantize_codebooks"); a.extra = e->PF(DEC + "extra_embeds.weight");
         a.tokpos = e->PF(DEC + "token_embed_positions.weight"); a.cond = e->PF(DEC + "cond_embed.weight");
         a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
+        a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
         tm.begin(0); gemv(e, a, s); tm.end();
     }
     for (int l = 0; l < c.layers; ++l) {
@@ -484,7 +496,7 @@ void validate_config(const ma_config& c) {
     if (c.n_points < 1 || c.num_latents < 1 || c.layers < 1 || c.enc_layers < 0 || c.shape_layers < 0 || c.tok_layers < 0) bad("non-positive size");
     if (c.n_max_faces < 1 || c.n_max_faces > c.tok_max_pos) bad("n_max_faces out of range");
     if (c.num_latents + 1 + c.n_max_faces * 9 + 2 > c.max_positions) bad("max_positions too small for cond_length + 9*n_max_faces + 2");
-    if (c.max_batch < 1 || c.kv_splits < 1 || c.kv_splits > ATTN_MAX_SPLITS || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
+    if (c.max_batch < 1 || c.kv_splits < 0 || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
 }
 
 void build_engine(ma_engine* e) {
@@ -503,9 +515,9 @@ void build_engine(ma_engine* e) {
     e->d_e = e->dmalloc<float>(H); e->d_q = e->dmalloc<float>(H); e->d_attn = e->dmalloc<float>(H);
     e->d_ypre1 = e->dmalloc<float>(H); e->d_ypre2 = e->dmalloc<float>(H); e->d_h0 = e->dmalloc<float>(H); e->d_h1 = e->dmalloc<float>(H);
     e->d_ffn = e->dmalloc<float>(c.ffn); e->d_logits = e->dmalloc<float>(e->V);
-    e->d_part = e->dmalloc<float>((size_t)c.kv_splits * c.heads * ATTN_PART_STRIDE);
+    e->d_part = e->dmalloc<float>(attn_workspace_floats(c.heads));
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
-    e->d_pval = e->dmalloc<float>(e->n_parts); e->d_pidx = e->dmalloc<int>(e->n_parts);
+    e->d_pval = e->dmalloc<float>(e->V); e->d_pidx = e->dmalloc<int>(e->V);        // >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(1); e->d_tokens = e->dmalloc<long long>(e->maxnew);
     HIP_CHECK(hipMemset(e->d_st, 0, sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_flag), 64));
@@ -606,8 +618,14 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         const std::string n = name;
         if (n == "gemm_impl") e->opt_gemm_impl = (int)value;
         else if (n == "prefill_stepwise") e->opt_prefill_stepwise = (int)value;
-        else if (n == "use_graph") {
-            e->cfg.use_graph = (int)value;
+        else if (n == "use_graph") e->cfg.use_graph = (int)value;
+        else if (n == "gemv_rpw") {
+            if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1 or 2");
+            gemv_rpw_big() = (int)value;
+            e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, e->cfg.hidden) : gemv_num_blocks<float>(e->V, e->cfg.hidden);
+            // the captured step embeds grids and arguments: drop it, the next generate() re-captures
+            if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+            if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
         } else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
 }
@@ -849,23 +867,26 @@ int ma_op_attention(const float* Q, int q_rs, int q_hs, const float* K, int k_rs
     });
 }
 
-int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int splits, float* out,
+int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, float* out,
                            void* workspace, void* stream) {
     return guarded(nullptr, [&] {
-        if (!q || !kcache || !vcache || !out || !workspace || len < 1 || len > max_seq || splits < 1 || splits > ATTN_MAX_SPLITS) throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: bad arguments");
+        if (!q || !kcache || !vcache || !out || !workspace || H < 1 || len < 1 || len > max_seq) throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: bad arguments");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        float* part = reinterpret_cast<float*>(workspace);
-        if (kvdtype == MA_DTYPE_BF16)
-            hipLaunchKernelGGL((attn_decode_kernel<bf16_t>), dim3(splits, H), dim3(256), 0, s, q, reinterpret_cast<const bf16_t*>(kcache),
-                               reinterpret_cast<const bf16_t*>(vcache), max_seq, (const DecState*)nullptr, len, 1, part);
-        else if (kvdtype == MA_DTYPE_F32)
-            hipLaunchKernelGGL((attn_decode_kernel<float>), dim3(splits, H), dim3(256), 0, s, q, reinterpret_cast<const float*>(kcache),
-                               reinterpret_cast<const float*>(vcache), max_seq, (const DecState*)nullptr, len, 0, part);
+        float* ws = reinterpret_cast<float*>(workspace);
+        hipError_t r;
+        if (kvdtype == MA_DTYPE_BF16) r = launch_attn_decode<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, ws, s);
+        else if (kvdtype == MA_DTYPE_F32) r = launch_attn_decode<float>(q, kcache, vcache, H, max_seq, nullptr, len, 0, ws, s);
         else throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: kvdtype");
-        HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(H), dim3(64), 0, s, part, splits, out);
+        HIP_CHECK(r);
+        // in the engine the merge of the split partials is the prologue of the out_proj GEMV; here it runs on its own
+        hipLaunchKernelGGL(attn_merge_kernel, dim3(ceil_div(H * 16, 256)), dim3(256), 0, s, ws, H, out);
         HIP_CHECK(hipGetLastError());
     });
+}
+
+size_t ma_decode_attention_workspace_bytes(int H) {
+    if (H < 1) return 0;
+    return attn_workspace_floats(H) * sizeof(float);
 }
 
 // ---- measurement ---------------------------------------------------------------------------------------------------
@@ -920,6 +941,37 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
             out->step_ms_graph = ms / steps;
         }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    });
+}
+
+int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launches, int max_blocks, int32_t* kinds, int32_t* blocks, int32_t* n_launches,
+                    void* stream) {
+    if (!e || !host_out || !kinds || !blocks || !n_launches || max_launches < 1 || max_blocks < 1) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e);
+        if (kv_len < e->T + 1 || kv_len + 16 > e->maxseq) throw MaError(MA_ERR_INVALID, "kv_len out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
+        sc.suppress_eos = 1;
+        init_state(e, s, sc, 0, e->maxnew);
+        hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5);
+        HIP_CHECK(hipGetLastError());
+        const size_t n64 = (size_t)max_launches * max_blocks * 4;
+        unsigned long long* d_tr = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_tr), n64 * sizeof(unsigned long long)));
+        try {
+            HIP_CHECK(hipMemsetAsync(d_tr, 0, n64 * sizeof(unsigned long long), s));
+            StepTimer none;
+            for (int i = 0; i < 3; ++i) enqueue_decode_step(e, s, -1, none);            // warm: clocks, caches
+            std::vector<int> k, b;
+            StepTimer tm; tm.tr = d_tr; tm.tr_max_launches = max_launches; tm.tr_max_blocks = max_blocks; tm.tr_kind = &k; tm.tr_blocks = &b;
+            enqueue_decode_step(e, s, -1, tm);
+            HIP_CHECK(hipMemcpyAsync(host_out, d_tr, n64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            *n_launches = (int)k.size();
+            for (size_t i = 0; i < k.size(); ++i) { kinds[i] = k[i]; blocks[i] = b[i]; }
+        } catch (...) { (void)hipFree(d_tr); throw; }
+        HIP_CHECK(hipFree(d_tr));
     });
 }
 

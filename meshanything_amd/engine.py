@@ -203,9 +203,20 @@ class Engine:
     def profile_decode(self, kv_len: int, steps: int = 4) -> Dict[str, object]:
         kt = _lib.KernelTiming()
         self._check(self.lib.ma_profile_decode(self.h, kv_len, steps, C.byref(kt), _stream_ptr()))
-        names = ["gemv", "attn_decode", "attn_combine", "pick"]
+        names = ["gemv", "attn_decode", "unused", "pick"]
         return {"launches": {n: kt.launches[i] for i, n in enumerate(names)}, "ms": {n: kt.ms[i] for i, n in enumerate(names)},
                 "step_ms_graph": kt.step_ms_graph, "step_ms_eager": kt.step_ms_eager, "steps": steps, "kv_len": kv_len}
+
+
+    def trace_decode(self, kv_len: int, max_launches: int = 160, max_blocks: int = 2560) -> Dict[str, np.ndarray]:
+        """In-kernel timeline of one eager decode step (diagnostics): ticks of the 100 MHz real-time counter."""
+        out = np.zeros((max_launches, max_blocks, 4), dtype=np.uint64)
+        kinds = np.zeros(max_launches, dtype=np.int32)
+        blocks = np.zeros(max_launches, dtype=np.int32)
+        n = C.c_int32()
+        self._check(self.lib.ma_trace_decode(self.h, kv_len, C.c_void_p(out.ctypes.data), max_launches, max_blocks,
+                                             C.c_void_p(kinds.ctypes.data), C.c_void_p(blocks.ctypes.data), C.byref(n), _stream_ptr()))
+        return {"ticks": out[:n.value], "kinds": kinds[:n.value], "blocks": blocks[:n.value]}
 
 
 def build_engine(cfg: MAConfig, items: Iterable[Tuple[str, object]], device: int = 0) -> Engine:
