@@ -149,6 +149,12 @@ MA_API int  ma_engine_upload_arena(ma_engine *e, const void *host_arena, size_t 
  *   prefix   (B, cond_length, hidden) fp32     -- decoder prefix (may be NULL to skip)              */
 MA_API int  ma_encode(ma_engine *e, const void *pc, int pc_dtype, int B, float *latents, float *prefix, void *stream);
 
+/* the two halves of ma_encode's prefix stage on their own, under the reference's names:
+ * replaces: point_encoder.to_shape_latents(latents) (asl_pl_module.py:182-185): (B, num_latents, enc_width) -> same shape */
+MA_API int  ma_to_shape_latents(ma_engine *e, const float *latents, int B, float *out, void *stream);
+/* replaces: MeshAnything.process_point_feature(point_feature) (meshanything.py:125-132): (B, cond_length, enc_width) -> (B, cond_length, hidden) */
+MA_API int  ma_process_point_feature(ma_engine *e, const float *point_feature, int B, float *prefix, void *stream);
+
 /* replaces: transformer.generate(inputs_embeds=prefix, max_new_tokens=..., ...) (meshanything.py:143-162).
  *   tokens      (B, max_new_tokens) int64 device: new tokens only; finished rows padded with pad=2
  *   lengths     host (B): tokens generated per row including its eos
@@ -160,6 +166,10 @@ MA_API int  ma_generate(ma_engine *e, const float *prefix, int B, const ma_sampl
 /* replaces: meshanything.py:163-172 (eos-pad to 9F+2, drop first/last, specials -> -1, others -= 3).
  *   tokens (B, max_new_tokens) + n_generated  ->  ids (B, 9*n_max_faces) int64 in [-1, codebook_size) */
 MA_API int  ma_postprocess_tokens(ma_engine *e, const int64_t *tokens, int B, int n_generated, int64_t *ids, void *stream);
+
+/* replaces: MeshAnything.get_codes(indices) (meshanything.py:178-212): ids (B, 9F) in [-1, codebook) -> codes (B, 3F, codebook_dim)
+ * fp32, the sum of the three residual-VQ rows of every vertex (pad contributes 0) */
+MA_API int  ma_get_codes(ma_engine *e, const int64_t *ids, int B, float *codes, void *stream);
 
 /* replaces: get_codes (meshanything.py:178-212) + tokenizer(ids, codes, point_feature=latents) (50-80).
  *   coords (B, n_max_faces, 3, 3) fp32, NaN rows = invalid faces */

@@ -60,6 +60,9 @@ SIGNATURES = {
     "ma_pack_weights_host": (_I, [C.POINTER(CMAConfig), C.POINTER(TensorDesc), _I, _P, C.c_char_p, _I]),
     "ma_engine_upload_arena": (_I, [_P, _P, C.c_size_t]),
     "ma_encode": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "ma_to_shape_latents": (_I, [_P, _P, _I, _P, _P]),
+    "ma_process_point_feature": (_I, [_P, _P, _I, _P, _P]),
+    "ma_get_codes": (_I, [_P, _P, _I, _P, _P]),
     "ma_generate": (_I, [_P, _P, _I, C.POINTER(SampleCfg), _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ma_postprocess_tokens": (_I, [_P, _P, _I, _I, _P, _P]),
     "ma_detokenize": (_I, [_P, _P, _P, _I, _P, _P]),

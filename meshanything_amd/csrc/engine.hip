@@ -189,19 +189,26 @@ void encode_one(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, float
     lnrows(e, s, e->w_lat, W, SM + "encoder.ln_post.", 1e-5f, latents, W, T, W);
 }
 
-// process_point_feature (meshanything.py:125-132) incl. to_shape_latents (asl_pl_module.py:182-185) for ONE sample
-void prefix_one(ma_engine* e, hipStream_t s, const float* latents, float* prefix) {
+// to_shape_latents (asl_pl_module.py:182-185 -> sal_perceiver.py:383-396 pre_kl / mode() / post_kl, 273-275 transformer)
+// for ONE sample: lat (NL, ld) -> e->w_lat (NL, W)
+void shape_latents_one(ma_engine* e, hipStream_t s, const float* lat, int ld) {
     const ma_config& c = e->cfg;
-    const int W = c.enc_width, T = e->T, H = c.hidden, E = c.embed_dim, NL = c.num_latents;
-    const float* lat1 = latents + W;                                       // point_feature[:, 1:]
-    gemm(e, s, lat1, W, SM + "pre_kl.weight", SM + "pre_kl.bias", nullptr, 0, e->w_mean, E, NL, ACT_NONE);     // posterior.mode()
+    const int W = c.enc_width, E = c.embed_dim, NL = c.num_latents;
+    gemm(e, s, lat, ld, SM + "pre_kl.weight", SM + "pre_kl.bias", nullptr, 0, e->w_mean, E, NL, ACT_NONE);      // posterior.mode(): the mean half
     gemm(e, s, e->w_mean, E, SM + "post_kl.weight", SM + "post_kl.bias", nullptr, 0, e->w_lat, W, NL, ACT_NONE);
     for (int n = 0; n < c.shape_layers; ++n) miche_block(e, s, e->w_lat, NL, SM + "transformer.resblocks." + std::to_string(n) + ".");
+}
+
+// process_point_feature (meshanything.py:125-132) incl. to_shape_latents for ONE sample
+void prefix_one(ma_engine* e, hipStream_t s, const float* latents, float* prefix) {
+    const ma_config& c = e->cfg;
+    const int W = c.enc_width, H = c.hidden, NL = c.num_latents;
+    const float* lat1 = latents + W;                                       // point_feature[:, 1:]
+    shape_latents_one(e, s, lat1, W);
     copy2d(s, lat1, W, e->w_cat, 2 * W, NL, W);                            // cat([latents, shape_latents], -1)
     copy2d(s, e->w_lat, W, e->w_cat + W, 2 * W, NL, W);
     gemm(e, s, latents, W, "cond_head_proj.weight", "cond_head_proj.bias", nullptr, 0, prefix, H, 1, ACT_NONE);
     gemm(e, s, e->w_cat, 2 * W, "cond_proj.weight", "cond_proj.bias", nullptr, 0, prefix + H, H, NL, ACT_NONE);
-    (void)T;
 }
 
 // ------------------------------------------------------------------------------------------------ decoder
@@ -760,6 +767,43 @@ int ma_encode(ma_engine* e, const void* pc, int pc_dtype, int B, float* latents,
             float* lat = latents + (size_t)b * e->T * e->cfg.enc_width;
             encode_one(e, s, reinterpret_cast<const char*>(pc) + b * pstride, pc_dtype, lat);
             if (prefix) prefix_one(e, s, lat, prefix + (size_t)b * e->T * e->cfg.hidden);
+        }
+    });
+}
+
+int ma_to_shape_latents(ma_engine* e, const float* latents, int B, float* out, void* stream) {
+    if (!e || !latents || !out) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const size_t n = (size_t)e->cfg.num_latents * e->cfg.enc_width;
+        for (int b = 0; b < B; ++b) {
+            shape_latents_one(e, s, latents + b * n, e->cfg.enc_width);
+            copy2d(s, e->w_lat, e->cfg.enc_width, out + b * n, e->cfg.enc_width, e->cfg.num_latents, e->cfg.enc_width);
+        }
+    });
+}
+
+int ma_process_point_feature(ma_engine* e, const float* point_feature, int B, float* prefix, void* stream) {
+    if (!e || !point_feature || !prefix) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        for (int b = 0; b < B; ++b)
+            prefix_one(e, s, point_feature + (size_t)b * e->T * e->cfg.enc_width, prefix + (size_t)b * e->T * e->cfg.hidden);
+    });
+}
+
+int ma_get_codes(ma_engine* e, const int64_t* ids, int B, float* codes, void* stream) {
+    if (!e || !ids || !codes) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e); check_batch(e, B);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const int D = e->cfg.codebook_dim, nf = e->nf;
+        for (int b = 0; b < B; ++b) {
+            hipLaunchKernelGGL(codes_gather_kernel, dim3(ceil_div(nf * 3 * D, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(ids) + (size_t)b * nf * 9,
+                               e->PF(DEC + "quantize_codebooks"), D, nf, codes + (size_t)b * nf * 3 * D, e->w_mask);
+            HIP_CHECK(hipGetLastError());
         }
     });
 }

@@ -120,6 +120,33 @@ class Engine:
         self._check(self.lib.ma_encode(self.h, _ptr(x), dt, B, _ptr(latents), _ptr(prefix), _stream_ptr()))
         return latents, prefix
 
+    def to_shape_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """point_encoder.to_shape_latents (asl_pl_module.py:182-185): (B, 256, 768) -> (B, 256, 768)."""
+        cfg = self.cfg
+        x = latents.to(self.device, torch.float32).contiguous()
+        assert x.dim() == 3 and x.shape[1] == cfg.num_latents and x.shape[2] == cfg.enc_width, x.shape
+        out = torch.empty_like(x)
+        self._check(self.lib.ma_to_shape_latents(self.h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr()))
+        return out
+
+    def process_point_feature(self, point_feature: torch.Tensor) -> torch.Tensor:
+        """MeshAnything.process_point_feature (meshanything.py:125-132): (B, 257, 768) -> (B, 257, 1024)."""
+        cfg = self.cfg
+        x = point_feature.to(self.device, torch.float32).contiguous()
+        assert x.dim() == 3 and x.shape[1] == cfg.cond_length and x.shape[2] == cfg.enc_width, x.shape
+        out = torch.empty(x.shape[0], cfg.cond_length, cfg.hidden, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ma_process_point_feature(self.h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr()))
+        return out
+
+    def get_codes(self, ids: torch.Tensor) -> torch.Tensor:
+        """MeshAnything.get_codes (meshanything.py:178-212): ids (B, 9F) -> (B, 3F, codebook_dim)."""
+        cfg = self.cfg
+        ids = ids.to(self.device, torch.int64).contiguous()
+        assert ids.dim() == 2 and ids.shape[1] == cfg.n_max_faces * 9, ids.shape
+        out = torch.empty(ids.shape[0], cfg.n_max_faces * 3, cfg.codebook_dim, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ma_get_codes(self.h, _ptr(ids), ids.shape[0], _ptr(out), _stream_ptr()))
+        return out
+
     def _sample_cfg(self, sampling: bool, max_new_tokens: Optional[int], suppress_eos: bool, uniforms: Optional[torch.Tensor],
                     seed: int, check_every: int, top_k: int, top_p: float) -> Tuple[_lib.SampleCfg, object]:
         sc = _lib.SampleCfg()
