@@ -113,19 +113,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from meshanything_amd.engine import Engine
+    from meshanything_amd import dp
     cfg = MAConfig.full(dtype=DTYPE_BF16 if args.dtype == "bf16" else DTYPE_F32, n_max_faces=args.faces, max_batch=1)
     eng = Engine(cfg, local_rank)
-    sd = None
+    sd = {}
     t_load = time.time()
-    if rank == 0:
-        sd = synthetic_state_dict(cfg)                      # random-init weights in the reference key layout (no network)
-        eng.load_weights(sd.items())
-    if world > 1:
-        # weights travel once, rank 0 -> all, as ONE RCCL broadcast of the packed arena over xGMI
-        arena = eng.arena_tensor()
-        dist.broadcast(arena, src=0)
-        torch.cuda.synchronize()
-        eng.mark_weights_loaded()
+
+    def items():                                            # only called on rank 0
+        sd.update(synthetic_state_dict(cfg))                # random-init weights in the reference key layout (no network)
+        return sd.items()
+    # weights travel once, rank 0 -> all, as ONE RCCL broadcast of the packed arena over xGMI
+    dp.load_weights_dp(eng, items, rank, world)
     t_load = time.time() - t_load
 
     if rank == 0:
@@ -171,22 +169,29 @@ def main():
         ev[3].record()
         torch.cuda.synchronize()
         phases = {"encode_ms": ev[0].elapsed_time(ev[1]), "generate_ms": ev[1].elapsed_time(ev[2]), "detokenize_ms": ev[2].elapsed_time(ev[3])}
-        # ---- roofline of the dominant kernel: the weight-streaming GEMV (HIP events around every launch, mid-context) ----
+        # ---- roofline of the dominant kernel: the weight-streaming GEMV.  HIP events (on the stream the kernels run on)
+        # around `profile_steps` steps with ONLY the GEMV launches enqueued: elapsed / launches = average launch duration,
+        # boundary to the next launch included -- the number a rocprofv3 kernel trace of the same command reports
+        # (profiles/).  Algorithmic bytes per launch = weight bytes of one step / GEMV launches of one step.
         mid = cfg.cond_length + cfg.max_new_tokens // 2
         prof = eng.profile_decode(mid, args.profile_steps)
         wbytes, launches = gemv_bytes_per_step(cfg, esz)
         n_l = prof["launches"]["gemv"]
+        assert n_l == launches * args.profile_steps, (n_l, launches)
         avg_ms = prof["ms"]["gemv"] / max(1, n_l)
         bytes_per_launch = wbytes / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         step_ms = prof["step_ms_graph"] or prof["step_ms_eager"]
         step_bytes = wbytes + kv_bytes_per_step(cfg, mid, esz)
-        roofline = {"bound": "hbm", "kernel": "gemv_kernel (decode weight stream)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us_events": round(avg_ms * 1e3, 3), "launches_timed": n_l,
+        attn_ms = prof["ms"]["attn_decode"] / max(1, prof["launches"]["attn_decode"])
+        roofline = {"bound": "hbm", "kernel": "gemv_kernel (decode weight stream, 98 launches per step)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": n_l,
                     "decode_step_ms_graph": round(prof["step_ms_graph"], 4), "decode_step_ms_eager": round(prof["step_ms_eager"], 4),
                     "decode_step_GBps_at_mid_context": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
-                    "per_class_ms_per_step": {k: round(v / args.profile_steps, 4) for k, v in prof["ms"].items()}}
+                    "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "attn_decode": {"kv_len": mid, "avg_launch_us": round(attn_ms * 1e3, 3),
+                                    "GBps": round(kv_bytes_per_step(cfg, mid, esz) / cfg.layers / (attn_ms * 1e-3) / 1e9, 1)}}
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc)[None])

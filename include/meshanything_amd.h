@@ -202,9 +202,11 @@ MA_API int  ma_op_decode_attention(int kvdtype, const float *q, const void *kcac
 MA_API size_t ma_decode_attention_workspace_bytes(int H);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
-/* Time the decode-step kernels with HIP events on `stream`: runs `steps` decode steps eagerly at KV length
- * `kv_len` (cache contents arbitrary) and reports, per kernel class, launches and summed event-bracketed ms.
- * Classes: 0 gemv (all weight-streaming launches; out_proj includes the split-KV merge), 1 decode attention, 2 unused, 3 pick/sample. */
+/* Time the decode step with HIP events on `stream` at KV length `kv_len` (cache contents arbitrary): `steps` back-to-back
+ * steps between ONE event pair, (a) eager, (b) as graph replays, (c) once per kernel class with only that class's launches
+ * enqueued, so ms[c] / launches[c] is that class's average launch duration including the boundary to the next launch
+ * (the view a rocprofv3 kernel trace gives).  Classes: 0 gemv (all weight-streaming launches; out_proj includes the
+ * split-KV merge), 1 decode attention, 3 pick/sample. */
 typedef struct ma_kernel_timing { int32_t launches[8]; float ms[8]; float step_ms_graph; float step_ms_eager; } ma_kernel_timing;
 MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_timing *out, void *stream);
 

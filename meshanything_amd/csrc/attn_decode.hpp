@@ -21,7 +21,7 @@ namespace ma {
 constexpr int ATTN_NCHUNK = 16;        // split factor (partials per head)
 
 // workspace: ML[heads][NCHUNK][2] (m, l) followed by O[heads][NCHUNK][64]
-inline size_t attn_workspace_floats(int heads) { return (size_t)heads * ATTN_NCHUNK * (2 + 64); }
+__host__ __device__ inline size_t attn_workspace_floats(int heads) { return (size_t)heads * ATTN_NCHUNK * (2 + 64); }
 
 // ---- consumer side: merge the partials of head h for the four dims d0..d0+3 ----------------------------------------
 __device__ inline void attn_partials_load(const float* ws, int H, int h, int d0, f32x4 (&pml)[ATTN_NCHUNK / 2], f32x4 (&po)[ATTN_NCHUNK]) {
@@ -78,16 +78,21 @@ template <typename KT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
                                                           const KT* __restrict__ vc, int max_seq, const DecState* st,
                                                           int len_override, int round_q, float* __restrict__ ws,
-                                                          unsigned long long* trace) {
+                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride) {
     constexpr int EPL = 16 / sizeof(KT);     // elements per lane per 16-byte load
     constexpr int LPP = 64 / EPL;            // lanes per position
     constexpr int PPW = 64 / LPP;            // positions per wave-load
     constexpr int U = 32 / PPW;              // loads per lane per operand and round: 32 positions per wave
     constexpr int NS = 4 * PPW;              // softmax states per block
-    const int c = blockIdx.x, h = blockIdx.y, H = gridDim.y;
+    const int c = blockIdx.x, h = blockIdx.y, H = gridDim.y, brow = blockIdx.z;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int slot = lane / LPP, dsub = lane % LPP;
     if (trace && threadIdx.x == 0) trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    // batch row (grid.z): its query, its cache planes, its partials, its state
+    q += (size_t)brow * q_stride;
+    kc += (size_t)brow * kv_row_stride;
+    vc += (size_t)brow * kv_row_stride;
+    ws += (size_t)brow * attn_workspace_floats(H);
 
     // q does not depend on the length: its load goes out together with the state's
     float qv[EPL];
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             qv[e] = t.x; qv[e + 1] = t.y; qv[e + 2] = t.z; qv[e + 3] = t.w;
         }
     }
-    const int len = len_override >= 0 ? len_override : st->pos + 1;
+    const int len = len_override >= 0 ? len_override : st[brow].pos + 1;
     const int per = (len + ATTN_NCHUNK - 1) / ATTN_NCHUNK;
     const int start = c * per;
     const int end = min(len, start + per);
@@ -223,9 +228,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 
 template <typename KT>
 inline hipError_t launch_attn_decode(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
-                                     int round_q, float* workspace, hipStream_t s, unsigned long long* trace = nullptr) {
-    hipLaunchKernelGGL((attn_decode_kernel<KT>), dim3(ATTN_NCHUNK, H), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc), reinterpret_cast<const KT*>(vc),
-                       max_seq, st, len_override, round_q, workspace, trace);
+                                     int round_q, float* workspace, hipStream_t s, unsigned long long* trace = nullptr, int batch = 1,
+                                     int q_stride = 0, size_t kv_row_stride = 0) {
+    hipLaunchKernelGGL((attn_decode_kernel<KT>), dim3(ATTN_NCHUNK, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc), reinterpret_cast<const KT*>(vc),
+                       max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride);
     return hipGetLastError();
 }
 

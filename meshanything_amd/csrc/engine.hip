@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <exception>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -66,21 +67,21 @@ struct ma_engine {
     int T = 0, V = 0, maxnew = 0, maxseq = 0, nf = 0, S = 0;
     bool bf16 = true;
     size_t kv_elem = 2;
-    char* kv = nullptr;              // [layers][2][heads][maxseq][64] of KT
+    char* kv = nullptr;              // [max_batch][layers][2][heads][maxseq][64] of KT
     size_t kv_plane = 0;             // bytes of one K (or V) plane of one layer
+    size_t kv_row_bytes = 0;         // bytes of one batch row's planes (2 * layers * kv_plane)
 
     // decode-step buffers
-    float *d_e = nullptr, *d_q = nullptr, *d_attn = nullptr, *d_ypre1 = nullptr, *d_ypre2 = nullptr, *d_h0 = nullptr, *d_h1 = nullptr,
+    float *d_e = nullptr, *d_q = nullptr, *d_ypre1 = nullptr, *d_ypre2 = nullptr, *d_h0 = nullptr, *d_h1 = nullptr,
           *d_ffn = nullptr, *d_logits = nullptr, *d_part = nullptr, *d_pval = nullptr;
     int* d_pidx = nullptr;
     int n_parts = 0;
-    DecState* d_st = nullptr;
-    long long* d_tokens = nullptr;
-    int* h_flag = nullptr;           // pinned
-    long long* h_tokens = nullptr;   // pinned (maxnew)
+    DecState* d_st = nullptr;        // one record per batch row
+    DecState* h_state = nullptr;     // pinned (max_batch)
+    long long* h_tokens = nullptr;   // pinned (max_batch * maxnew)
     std::vector<DecLayerPtrs> dl;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
+    std::map<int, hipGraph_t> graph;           // one captured decode step per batch size
+    std::map<int, hipGraphExec_t> gexec;
     hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the caller's may be the legacy null stream)
 
     // dense-phase workspace (one sample at a time)
@@ -95,6 +96,7 @@ struct ma_engine {
     // options
     int opt_gemm_impl = 0;           // 0 MFMA, 1 VALU reference kernel
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
+    int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
 
     template <typename Tp> Tp* dmalloc(size_t n) {
         void* p = nullptr;
@@ -108,8 +110,8 @@ struct ma_engine {
         return arena + L.entries[it->second].offset;
     }
     const float* PF(const std::string& name) const { return reinterpret_cast<const float*>(P(name)); }
-    char* kplane(int layer) const { return kv + (size_t)(2 * layer) * kv_plane; }
-    char* vplane(int layer) const { return kv + (size_t)(2 * layer + 1) * kv_plane; }
+    char* kplane(int row, int layer) const { return kv + (size_t)row * kv_row_bytes + (size_t)(2 * layer) * kv_plane; }
+    char* vplane(int row, int layer) const { return kv + (size_t)row * kv_row_bytes + (size_t)(2 * layer + 1) * kv_plane; }
 };
 
 namespace {
@@ -217,13 +219,12 @@ void gemv_launch(const GemvArgs& a, hipStream_t s) {
     hipError_t r = launch_gemv<WT>(a, s);
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
 }
-void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s) { if (e->bf16) gemv_launch<bf16_t>(a, s); else gemv_launch<float>(a, s); }
 int gemv_blocks(ma_engine* e, int N, int K) { return e->bf16 ? gemv_num_blocks<bf16_t>(N, K) : gemv_num_blocks<float>(N, K); }
 
-struct StepTimer {                    // optional per-launch HIP events (ma_profile_decode) / in-kernel timestamps (ma_trace_decode)
-    std::vector<hipEvent_t>* ev = nullptr;
-    std::vector<int>* cls = nullptr;
-    hipStream_t s = nullptr;
+struct StepTimer {                    // launch filter (ma_profile_decode) / in-kernel timestamps (ma_trace_decode)
+    int only_cls = -1;                // >= 0: enqueue only the launches of this class (0 gemv, 1 attention, 3 pick)
+    int launched[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool on(int c) { if (only_cls >= 0 && c != only_cls) return false; launched[c]++; return true; }
     unsigned long long* tr = nullptr; int tr_max_launches = 0, tr_max_blocks = 0;
     std::vector<int>* tr_kind = nullptr; std::vector<int>* tr_blocks = nullptr;
     // slot for the next launch's timestamps (kind: 0 embed, 1 qkv, 2 attention, 3 out_proj, 4 fc1, 5 fc2, 6 lm_head)
@@ -233,139 +234,166 @@ struct StepTimer {                    // optional per-launch HIP events (ma_prof
         tr_kind->push_back(kind); tr_blocks->push_back(blocks);
         return p;
     }
-    void begin(int c) { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); cls->push_back(c); } }
-    void end() { if (ev) { hipEvent_t a; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventRecord(a, s)); ev->push_back(a); } }
 };
 
-GemvArgs gemv_base(ma_engine* e) {
+// ---- batched decode: rows r0 .. r0+B-1 of the engine's per-row buffers.  Row b owns the b-th slice of every activation
+// buffer, its own KV planes, its own DecState record and its own output token row; the weights are shared.
+struct Rows { int r0 = 0, B = 1; };
+
+GemvArgs gemv_base(ma_engine* e, Rows rw) {
     GemvArgs a{};
     a.round_x = e->bf16 ? 1 : 0;
-    a.st = e->d_st;
+    a.st = e->d_st + rw.r0;
     a.act = ACT_NONE;
     a.epi = EPI_PLAIN;
     return a;
 }
+void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s, int B) {
+    hipError_t r = e->bf16 ? launch_gemv<bf16_t>(a, s, B) : launch_gemv<float>(a, s, B);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
+}
 
-// one OPT layer of one decode step.  `x_in` = this layer's input before its (optional) LayerNorm prologue.
-void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm) {
+// one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
+void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
     const ma_config& c = e->cfg;
-    const int H = c.hidden;
+    const int H = c.hidden, B = rw.B;
+    const size_t r0 = rw.r0;
     const DecLayerPtrs& w = e->dl[l];
-    const float* resid = ln_g ? e->d_h0 : x_in;
+    float* h0 = e->d_h0 + r0 * H; float* q = e->d_q + r0 * H; float* y1 = e->d_ypre1 + r0 * H; float* y2 = e->d_ypre2 + r0 * H;
+    float* h1 = e->d_h1 + r0 * H; float* ffn = e->d_ffn + r0 * c.ffn; float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
+    const float* resid = ln_g ? h0 : x_in;
+    const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     {   // q,k,v = W h + b ; k,v appended to the cache in place ([3p] OPTAttention; 4.39.3 grows it with torch.cat)
-        GemvArgs a = gemv_base(e);
-        a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? e->d_h0 : nullptr;
-        a.y = e->d_q; a.N = 3 * H; a.K = H; a.epi = EPI_QKV; a.kcache = e->kplane(l); a.vcache = e->vplane(l); a.H = H; a.max_seq = e->maxseq;
+        GemvArgs a = gemv_base(e, rw);
+        a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.x_stride = H; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? h0 : nullptr; a.xn_stride = H;
+        a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems;
+        a.H = H; a.max_seq = e->maxseq;
         a.trace = tm.trace_slot(1, gemv_blocks(e, a.N, a.K));
-        tm.begin(0); gemv(e, a, s); tm.end();
+        if (tm.on(0)) gemv(e, a, s, B);
     }
-    tm.begin(1);
-    {
+    if (tm.on(1)) {
         unsigned long long* tr = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
-        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(e->d_q, e->kplane(l), e->vplane(l), c.heads, e->maxseq, e->d_st, len_override, 1, e->d_part, s, tr)
-                               : launch_attn_decode<float>(e->d_q, e->kplane(l), e->vplane(l), c.heads, e->maxseq, e->d_st, len_override, 0, e->d_part, s, tr);
+        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems)
+                               : launch_attn_decode<float>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 0, part, s, tr, B, H, kv_row_elems);
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
     }
-    tm.end();
     {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
-        GemvArgs a = gemv_base(e);
+        GemvArgs a = gemv_base(e, rw);
         // the attention output is never materialised: this GEMV's prologue merges the split-KV partials
-        a.W = w.o_w; a.bias = w.o_b; a.x = nullptr; a.attn_ws = e->d_part; a.attn_heads = c.heads; a.res = resid; a.y = e->d_ypre1; a.N = H; a.K = H;
+        a.W = w.o_w; a.bias = w.o_b; a.x = nullptr; a.attn_ws = part; a.attn_ws_stride = attn_workspace_floats(c.heads); a.attn_heads = c.heads;
+        a.res = resid; a.res_stride = H; a.y = y1; a.y_stride = H; a.N = H; a.K = H;
         a.trace = tm.trace_slot(3, gemv_blocks(e, a.N, a.K));
-        tm.begin(0); gemv(e, a, s); tm.end();
+        if (tm.on(0)) gemv(e, a, s, B);
     }
     {   // f = relu(W1 LN1(y1) + b1); h1 = LN1(y1) kept for the residual
-        GemvArgs a = gemv_base(e);
-        a.W = w.fc1_w; a.bias = w.fc1_b; a.x = e->d_ypre1; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = e->d_h1;
-        a.y = e->d_ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
+        GemvArgs a = gemv_base(e, rw);
+        a.W = w.fc1_w; a.bias = w.fc1_b; a.x = y1; a.x_stride = H; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = h1; a.xn_stride = H;
+        a.y = ffn; a.y_stride = c.ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
         a.trace = tm.trace_slot(4, gemv_blocks(e, a.N, a.K));
-        tm.begin(0); gemv(e, a, s); tm.end();
+        if (tm.on(0)) gemv(e, a, s, B);
     }
     {   // y2 = h1 + W2 f + b2
-        GemvArgs a = gemv_base(e);
-        a.W = w.fc2_w; a.bias = w.fc2_b; a.x = e->d_ffn; a.res = e->d_h1; a.y = e->d_ypre2; a.N = H; a.K = c.ffn;
+        GemvArgs a = gemv_base(e, rw);
+        a.W = w.fc2_w; a.bias = w.fc2_b; a.x = ffn; a.x_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H; a.N = H; a.K = c.ffn;
         a.trace = tm.trace_slot(5, gemv_blocks(e, a.N, a.K));
-        tm.begin(0); gemv(e, a, s); tm.end();
+        if (tm.on(0)) gemv(e, a, s, B);
     }
 }
 
-void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, const float* ln_g, const float* ln_b, StepTimer& tm) {
-    GemvArgs a = gemv_base(e);
-    a.W = e->P("transformer.lm_head.weight"); a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
-    a.y = e->d_logits; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD; a.part_val = e->d_pval; a.part_idx = e->d_pidx;
+void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw) {
+    GemvArgs a = gemv_base(e, rw);
+    a.W = e->P("transformer.lm_head.weight"); a.x = x; a.x_stride = x_stride; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+    a.y = e->d_logits + (size_t)rw.r0 * e->V; a.y_stride = e->V; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD;
+    a.part_val = e->d_pval + (size_t)rw.r0 * e->V; a.part_idx = e->d_pidx + (size_t)rw.r0 * e->V; a.part_stride = e->V;
     a.trace = tm.trace_slot(6, gemv_blocks(e, a.N, a.K));
-    tm.begin(0); gemv(e, a, s); tm.end();
+    if (tm.on(0)) gemv(e, a, s, rw.B);
 }
 
-void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm) {
-    tm.begin(3);
-    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(256), (size_t)e->V * sizeof(float), s, e->d_logits, e->V, e->d_pval, e->d_pidx, e->n_parts, e->d_st, e->d_tokens, e->T);
+void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm, Rows rw) {
+    if (!tm.on(3)) return;
+    hipLaunchKernelGGL(pick_kernel, dim3(rw.B), dim3(256), (size_t)e->V * sizeof(float), s, e->d_logits + (size_t)rw.r0 * e->V, e->V,
+                       e->d_pval + (size_t)rw.r0 * e->V, e->d_pidx + (size_t)rw.r0 * e->V, e->n_parts, e->V, e->d_st + rw.r0,
+                       e->w_tokens + (size_t)rw.r0 * e->maxnew, e->maxnew, e->T);
     HIP_CHECK(hipGetLastError());
-    tm.end();
 }
 
-// One full decode step (shape_opt.py:318-328 embedding branch -> 24 layers -> lm_head -> pick).  Replayable: no host-side
-// step-dependent argument.
-void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTimer& tm) {
+// One full decode step (shape_opt.py:318-328 embedding branch -> 24 layers -> lm_head -> pick) for rows r0..r0+B-1.
+// Replayable: no host-side step-dependent argument.
+void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTimer& tm, Rows rw = Rows{}) {
     const ma_config& c = e->cfg;
+    const int H = c.hidden;
+    float* de = e->d_e + (size_t)rw.r0 * H;
     {
-        GemvArgs a = gemv_base(e);
-        a.W = e->P(DEC + "input_layer.weight"); a.bias = e->PF(DEC + "input_layer.bias"); a.y = e->d_e; a.N = c.hidden; a.K = c.codebook_dim;
+        GemvArgs a = gemv_base(e, rw);
+        a.W = e->P(DEC + "input_layer.weight"); a.bias = e->PF(DEC + "input_layer.bias"); a.y = de; a.y_stride = H; a.N = H; a.K = c.codebook_dim;
         a.epi = EPI_EMBED; a.codebook = e->PF(DEC + "quantize_codebooks"); a.extra = e->PF(DEC + "extra_embeds.weight");
         a.tokpos = e->PF(DEC + "token_embed_positions.weight"); a.cond = e->PF(DEC + "cond_embed.weight");
         a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
         a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
-        tm.begin(0); gemv(e, a, s); tm.end();
+        if (tm.on(0)) gemv(e, a, s, rw.B);
     }
+    const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
     for (int l = 0; l < c.layers; ++l) {
-        if (l == 0) enqueue_layer(e, s, 0, e->d_e, nullptr, nullptr, len_override, tm);
-        else enqueue_layer(e, s, l, e->d_ypre2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm);
+        if (l == 0) enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw);
+        else enqueue_layer(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm, rw);
     }
-    enqueue_lm_head(e, s, e->d_ypre2, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm);
-    enqueue_pick(e, s, tm);
+    enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw);
+    enqueue_pick(e, s, tm, rw);
 }
 
-void ensure_graph(ma_engine* e, hipStream_t) {
-    if (e->gexec || !e->cfg.use_graph) return;
+void drop_graphs(ma_engine* e) {
+    for (auto& kv : e->gexec) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : e->graph) if (kv.second) (void)hipGraphDestroy(kv.second);
+    e->gexec.clear(); e->graph.clear();
+}
+
+// one captured step per batch size (the grids depend on B)
+void ensure_graph(ma_engine* e, int B) {
+    if (!e->cfg.use_graph || e->gexec.count(B)) return;
     StepTimer none;
     if (!e->cap_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     hipStream_t s = e->cap_stream;
+    hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-        enqueue_decode_step(e, s, -1, none);
+        enqueue_decode_step(e, s, -1, none, Rows{0, B});
     } catch (...) {
-        hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(s, &g);
         if (g) (void)hipGraphDestroy(g);
         throw;
     }
-    HIP_CHECK(hipStreamEndCapture(s, &e->graph));
-    HIP_CHECK(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+    HIP_CHECK(hipStreamEndCapture(s, &g));
+    hipGraphExec_t ge = nullptr;
+    hipError_t r = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (r != hipSuccess) { (void)hipGraphDestroy(g); HIP_CHECK(r); }
+    e->graph[B] = g; e->gexec[B] = ge;
 }
 
-void launch_step(ma_engine* e, hipStream_t s) {
-    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec, s));
-    else { StepTimer none; enqueue_decode_step(e, s, -1, none); }
+void launch_step(ma_engine* e, hipStream_t s, int B) {
+    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s));
+    else { StepTimer none; enqueue_decode_step(e, s, -1, none, Rows{0, B}); }
 }
 
-// prefill: ShapeOPTDecoder.forward inputs_embeds branch (shape_opt.py:331-364) + 24 post-LN layers, causal, on the T prefix rows
-void prefill(ma_engine* e, hipStream_t s, const float* prefix) {
+// prefill of ONE row: ShapeOPTDecoder.forward inputs_embeds branch (shape_opt.py:331-364) + 24 post-LN layers, causal, on the
+// T prefix rows; fills the row's KV planes and leaves the row's first logits in d_logits[row]
+void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row) {
     const ma_config& c = e->cfg;
     const int T = e->T, H = c.hidden;
     StepTimer none;
+    const Rows rw{row, 1};
     float* h = e->w_x;                       // (T, H)
     add_rows(s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, T, H);
     if (e->opt_prefill_stepwise) {
         // debug path: feed the prefix rows through the decode-step kernels one position at a time
         for (int j = 0; j < T; ++j) {
-            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, 0, j, 0);
+            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st + row, 0, j, 0, 1);
             HIP_CHECK(hipGetLastError());
             for (int l = 0; l < c.layers; ++l) {
-                if (l == 0) enqueue_layer(e, s, 0, h + (size_t)j * H, nullptr, nullptr, -1, none);
-                else enqueue_layer(e, s, l, e->d_ypre2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, -1, none);
+                if (l == 0) enqueue_layer(e, s, 0, h + (size_t)j * H, nullptr, nullptr, -1, none, rw);
+                else enqueue_layer(e, s, l, e->d_ypre2 + (size_t)row * H, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, -1, none, rw);
             }
         }
-        enqueue_lm_head(e, s, e->d_ypre2, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, none);
+        enqueue_lm_head(e, s, e->d_ypre2 + (size_t)row * H, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, none, rw);
         return;
     }
     float* qkv = e->w_qkv;                   // (T, 3H)
@@ -377,9 +405,9 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix) {
         gemm(e, s, h, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * H, T, ACT_NONE);
         const int n = T * c.heads * 64;
         if (e->bf16) hipLaunchKernelGGL((kv_fill_kernel<bf16_t>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                        reinterpret_cast<bf16_t*>(e->kplane(l)), reinterpret_cast<bf16_t*>(e->vplane(l)));
+                                        reinterpret_cast<bf16_t*>(e->kplane(row, l)), reinterpret_cast<bf16_t*>(e->vplane(row, l)));
         else hipLaunchKernelGGL((kv_fill_kernel<float>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                reinterpret_cast<float*>(e->kplane(l)), reinterpret_cast<float*>(e->vplane(l)));
+                                reinterpret_cast<float*>(e->kplane(row, l)), reinterpret_cast<float*>(e->vplane(row, l)));
         HIP_CHECK(hipGetLastError());
         attention(e, s, qkv, 3 * H, 64, qkv + H, 3 * H, 64, qkv + 2 * H, 3 * H, 64, att, H, T, T, c.heads, 0);
         gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, y, H, T, ACT_NONE);
@@ -389,15 +417,16 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix) {
         lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, T, H);
     }
     // only the last prefix row feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
-    enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, nullptr, nullptr, none);
+    enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, 0, nullptr, nullptr, none, rw);
 }
 
-void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int row, int maxn) {
+// state records of rows 0..B-1: identical except for the row id and the row's slice of the injected uniforms
+void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int maxn) {
     DecState st{};
     st.t = 0; st.pos = e->T - 1; st.cur_tok = 0; st.finished = 0;
     st.suppress_eos = sc.suppress_eos; st.do_sample = sc.do_sample; st.top_k = sc.top_k; st.top_p = sc.top_p;
-    st.seed = sc.seed; st.uniforms = sc.uniforms ? sc.uniforms + (size_t)row * maxn : nullptr; st.row = row; st.max_new = maxn;
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, s, e->d_st, st);
+    st.seed = sc.seed; st.uniforms = sc.uniforms; st.row = 0; st.max_new = maxn;
+    hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, e->d_st, st, B);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -419,33 +448,43 @@ ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
     return r;
 }
 
-// generate() for ONE row: prefill, then step until eos / max_new_tokens.  Returns the row's length (incl. eos).
-int generate_one(ma_engine* e, hipStream_t s, const float* prefix, const ma_sample_cfg& sc, int row, long long* tokens_row) {
+// generate() for a batch of B rows: every row is prefilled, then all rows step together (they share the weight stream and
+// the cache position) until every row has emitted eos or max_new_tokens ([3p] GenerationMixin: a finished row keeps
+// stepping and emits pad).  tokens_out (B, maxnew) device; lengths host (B).  Returns the number of valid columns.
+int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, const ma_sample_cfg& sc, long long* tokens_out, int32_t* lengths) {
     const int maxn = sc.max_new_tokens;
-    hipLaunchKernelGGL(fill_tokens_kernel, dim3(ceil_div(e->maxnew, 256)), dim3(256), 0, s, e->d_tokens, (long long)TOK_PAD, e->maxnew);
+    const int total = B * e->maxnew;
+    hipLaunchKernelGGL(fill_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, e->w_tokens, (long long)TOK_PAD, total);
     HIP_CHECK(hipGetLastError());
-    ensure_graph(e, s);
-    init_state(e, s, sc, row, maxn);
-    prefill(e, s, prefix);
+    ensure_graph(e, B);
+    init_state(e, s, sc, B, maxn);
+    for (int b = 0; b < B; ++b) prefill(e, s, prefix + (size_t)b * e->T * e->cfg.hidden, b);
+    if (e->opt_prefill_stepwise) init_state(e, s, sc, B, maxn);         // the stepwise prefill used the state's pos field
     StepTimer none;
-    if (e->opt_prefill_stepwise) init_state(e, s, sc, row, maxn);       // the stepwise prefill used the state's pos field
-    enqueue_pick(e, s, none);                                          // token 0 (expected bos; dropped later, meshanything.py:166)
+    enqueue_pick(e, s, none, Rows{0, B});                                // token 0 (expected bos; dropped later, meshanything.py:166)
     int produced = 1;
     bool finished = false;
     while (produced < maxn && !finished) {
         const int burst = std::min(sc.check_every, maxn - produced);
-        for (int i = 0; i < burst; ++i) launch_step(e, s);
+        for (int i = 0; i < burst; ++i) launch_step(e, s, B);
         produced += burst;
-        HIP_CHECK(hipMemcpyAsync(e->h_flag, &e->d_st->finished, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(e->h_state, e->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        finished = *e->h_flag != 0;
+        finished = true;
+        for (int b = 0; b < B; ++b) finished = finished && e->h_state[b].finished != 0;
     }
-    HIP_CHECK(hipMemcpyAsync(e->h_tokens, e->d_tokens, (size_t)maxn * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(e->h_tokens, e->w_tokens, (size_t)total * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
-    int len = produced;
-    for (int i = 0; i < produced; ++i) if (e->h_tokens[i] == TOK_EOS) { len = i + 1; break; }
-    HIP_CHECK(hipMemcpyAsync(tokens_row, e->d_tokens, (size_t)e->maxnew * sizeof(long long), hipMemcpyDeviceToDevice, s));
-    return len;
+    int nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        const long long* row = e->h_tokens + (size_t)b * e->maxnew;
+        int len = produced;
+        for (int i = 0; i < produced; ++i) if (row[i] == TOK_EOS) { len = i + 1; break; }
+        if (lengths) lengths[b] = len;
+        nmax = std::max(nmax, len);
+    }
+    if (tokens_out != e->w_tokens) HIP_CHECK(hipMemcpyAsync(tokens_out, e->w_tokens, (size_t)total * sizeof(long long), hipMemcpyDeviceToDevice, s));
+    return nmax;
 }
 
 // ------------------------------------------------------------------------------------------------ detokenizer
@@ -515,20 +554,23 @@ void build_engine(ma_engine* e) {
     e->bf16 = c.dtype == MA_DTYPE_BF16; e->kv_elem = e->bf16 ? 2 : 4;
     HIP_CHECK(hipMalloc(&e->arena, e->L.bytes));
     HIP_CHECK(hipMemset(e->arena, 0, e->L.bytes));
+    const size_t MB = c.max_batch;
     e->kv_plane = (size_t)c.heads * e->maxseq * 64 * e->kv_elem;
-    HIP_CHECK(hipMalloc(&e->kv, e->kv_plane * 2 * c.layers));
-    HIP_CHECK(hipMemset(e->kv, 0, e->kv_plane * 2 * c.layers));
+    e->kv_row_bytes = e->kv_plane * 2 * c.layers;
+    HIP_CHECK(hipMalloc(&e->kv, e->kv_row_bytes * MB));
+    HIP_CHECK(hipMemset(e->kv, 0, e->kv_row_bytes * MB));
     const int H = c.hidden;
-    e->d_e = e->dmalloc<float>(H); e->d_q = e->dmalloc<float>(H); e->d_attn = e->dmalloc<float>(H);
-    e->d_ypre1 = e->dmalloc<float>(H); e->d_ypre2 = e->dmalloc<float>(H); e->d_h0 = e->dmalloc<float>(H); e->d_h1 = e->dmalloc<float>(H);
-    e->d_ffn = e->dmalloc<float>(c.ffn); e->d_logits = e->dmalloc<float>(e->V);
-    e->d_part = e->dmalloc<float>(attn_workspace_floats(c.heads));
+    // decode-step buffers: one slice per batch row
+    e->d_e = e->dmalloc<float>(MB * H); e->d_q = e->dmalloc<float>(MB * H);
+    e->d_ypre1 = e->dmalloc<float>(MB * H); e->d_ypre2 = e->dmalloc<float>(MB * H); e->d_h0 = e->dmalloc<float>(MB * H); e->d_h1 = e->dmalloc<float>(MB * H);
+    e->d_ffn = e->dmalloc<float>(MB * c.ffn); e->d_logits = e->dmalloc<float>(MB * e->V);
+    e->d_part = e->dmalloc<float>(MB * attn_workspace_floats(c.heads));
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
-    e->d_pval = e->dmalloc<float>(e->V); e->d_pidx = e->dmalloc<int>(e->V);        // >= blocks for any rows-per-block
-    e->d_st = e->dmalloc<DecState>(1); e->d_tokens = e->dmalloc<long long>(e->maxnew);
-    HIP_CHECK(hipMemset(e->d_st, 0, sizeof(DecState)));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_flag), 64));
-    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), (size_t)e->maxnew * sizeof(long long)));
+    e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
+    e->d_st = e->dmalloc<DecState>(MB);
+    HIP_CHECK(hipMemset(e->d_st, 0, MB * sizeof(DecState)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));
     // dense workspace, one sample
     const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S;
     const size_t rows_small = std::max(T, S);                       // rows of the latent / token streams
@@ -608,13 +650,12 @@ int ma_engine_create(ma_engine** out, const ma_config* cfg, int device) {
 void ma_engine_destroy(ma_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
-    if (e->graph) (void)hipGraphDestroy(e->graph);
+    drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->arena) (void)hipFree(e->arena);
     if (e->kv) (void)hipFree(e->kv);
-    if (e->h_flag) (void)hipHostFree(e->h_flag);
+    if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_tokens) (void)hipHostFree(e->h_tokens);
     delete e;
 }
@@ -626,13 +667,12 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         if (n == "gemm_impl") e->opt_gemm_impl = (int)value;
         else if (n == "prefill_stepwise") e->opt_prefill_stepwise = (int)value;
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
+        else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "gemv_rpw") {
             if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1 or 2");
             gemv_rpw_big() = (int)value;
             e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, e->cfg.hidden) : gemv_num_blocks<float>(e->V, e->cfg.hidden);
-            // the captured step embeds grids and arguments: drop it, the next generate() re-captures
-            if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
-            if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+            drop_graphs(e);                              // the captured steps embed grids and arguments: the next generate() re-captures
         } else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
 }
@@ -814,13 +854,8 @@ int ma_generate(ma_engine* e, const float* prefix, int B, const ma_sample_cfg* s
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const ma_sample_cfg sc = resolve_sample_cfg(e, sc_in);
-        int nmax = 0;
-        for (int b = 0; b < B; ++b) {
-            // rows are independent (no cross-batch op anywhere in meshanything.py:134-176): generated one after another in round 1
-            const int len = generate_one(e, s, prefix + (size_t)b * e->T * e->cfg.hidden, sc, b, reinterpret_cast<long long*>(tokens) + (size_t)b * e->maxnew);
-            if (lengths) lengths[b] = len;
-            nmax = std::max(nmax, len);
-        }
+        // rows are independent (no cross-batch op anywhere in meshanything.py:134-176) but step together: one weight stream per step
+        const int nmax = generate_batch(e, s, prefix, B, sc, reinterpret_cast<long long*>(tokens), lengths);
         HIP_CHECK(hipStreamSynchronize(s));
         if (n_generated) *n_generated = nmax;
     });
@@ -944,45 +979,44 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         std::memset(out, 0, sizeof(*out));
         ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
         sc.suppress_eos = 1;
-        ensure_graph(e, s);
+        const int B = std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch));
+        ensure_graph(e, B);
         auto reset = [&] {
-            init_state(e, s, sc, 0, e->maxnew);
+            init_state(e, s, sc, B, e->maxnew);
             // state as if t tokens had been generated and the cache held kv_len-1 rows
-            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5);
+            hipLaunchKernelGGL(set_pos_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5, B);
             HIP_CHECK(hipGetLastError());
         };
-        // (a) per-launch event brackets, eager
-        reset();
-        std::vector<hipEvent_t> ev; std::vector<int> cls;
-        StepTimer tm; tm.ev = &ev; tm.cls = &cls; tm.s = s;
-        for (int i = 0; i < steps; ++i) enqueue_decode_step(e, s, -1, tm);
-        HIP_CHECK(hipStreamSynchronize(s));
-        for (size_t i = 0; i < cls.size(); ++i) {
-            float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-            out->launches[cls[i]] += 1; out->ms[cls[i]] += ms;
-        }
-        for (hipEvent_t x : ev) (void)hipEventDestroy(x);
-        // (b) whole-step times: eager launches and graph replays, events around `steps` steps
         hipEvent_t a, b;
         HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-        StepTimer none;
-        reset();
-        HIP_CHECK(hipEventRecord(a, s));
-        for (int i = 0; i < steps; ++i) enqueue_decode_step(e, s, -1, none);
-        HIP_CHECK(hipEventRecord(b, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        float ms = 0.f;
-        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-        out->step_ms_eager = ms / steps;
-        if (e->gexec) {
+        // One event pair around `steps` back-to-back steps (no per-launch events: an event record between two launches
+        // costs more than the launch boundary it would measure).  only_cls >= 0 enqueues just that class of launches, so
+        // class time / launches is the average launch duration, boundary to the next launch included -- the same view as
+        // a rocprofv3 kernel trace of the replayed graph.  only_cls == -2: graph replays.
+        auto timed = [&](int only_cls, int* launches) -> float {
+            StepTimer tm; tm.only_cls = only_cls;
+            reset();
+            if (only_cls == -2) { HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s)); }                // warm
+            else { StepTimer w; w.only_cls = only_cls; enqueue_decode_step(e, s, -1, w, Rows{0, B}); }
             reset();
             HIP_CHECK(hipEventRecord(a, s));
-            for (int i = 0; i < steps; ++i) HIP_CHECK(hipGraphLaunch(e->gexec, s));
+            for (int i = 0; i < steps; ++i) {
+                if (only_cls == -2) HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s));
+                else enqueue_decode_step(e, s, -1, tm, Rows{0, B});
+            }
             HIP_CHECK(hipEventRecord(b, s));
             HIP_CHECK(hipStreamSynchronize(s));
+            float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-            out->step_ms_graph = ms / steps;
+            if (launches) *launches = only_cls >= 0 ? tm.launched[only_cls] : 0;
+            return ms;
+        };
+        out->step_ms_eager = timed(-1, nullptr) / steps;
+        if (e->cfg.use_graph) out->step_ms_graph = timed(-2, nullptr) / steps;
+        for (int cls : {0, 1, 3}) {
+            int n = 0;
+            out->ms[cls] = timed(cls, &n);
+            out->launches[cls] = n;
         }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     });
@@ -997,8 +1031,8 @@ int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launch
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
         sc.suppress_eos = 1;
-        init_state(e, s, sc, 0, e->maxnew);
-        hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5);
+        init_state(e, s, sc, 1, e->maxnew);
+        hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5, 1);
         HIP_CHECK(hipGetLastError());
         const size_t n64 = (size_t)max_launches * max_blocks * 4;
         unsigned long long* d_tr = nullptr;

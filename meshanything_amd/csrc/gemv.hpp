@@ -47,6 +47,9 @@ struct GemvArgs {
     const DecState* st;
     // PRO_ATTN: x = merge of the split-KV attention partials (attn_decode.hpp), K = attn_heads * 64
     const float* attn_ws; int attn_heads;
+    // batch: grid.y = batch row b.  Per-row operands advance by these element strides; the weights are shared (rows after
+    // the first find them in L2 / Infinity Cache).  kv_row_stride: elements between two rows' cache planes.
+    int x_stride, y_stride, res_stride, xn_stride, part_stride; size_t kv_row_stride; size_t attn_ws_stride;
     // diagnostics (ma_trace_decode): wave 0 of block b stores the 100 MHz real-time counter at four points into trace[b*4..]
     unsigned long long* trace;
 };
@@ -90,13 +93,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     const int my_row = row0 + lane;                      // row finished by this lane (lanes < RPW of the group's first wave)
     const bool fin = wk == 0 && lane < RPW && my_row < N;
     MA_TRACE(a.trace, 0);
+    // batch row: per-row operands (blockIdx.y = 0 and zero strides at batch 1)
+    const int brow = blockIdx.y;
+    a.y += (size_t)brow * a.y_stride;
+    if (a.x) a.x += (size_t)brow * a.x_stride;
+    if (a.res) a.res += (size_t)brow * a.res_stride;
+    if (a.xn_out) a.xn_out += (size_t)brow * a.xn_stride;
+    if (a.attn_ws) a.attn_ws += (size_t)brow * a.attn_ws_stride;
 
     // ---- (0) decode state: ONE scalar load of the whole record (no dependent scalar round trips) ------------------
     const float* x = a.x;
     int tok = 0, tstep = 0, pos = 0, skip = -1;
     bool skip_dot = false;
     if (a.epi != EPI_PLAIN) {
-        const DecState sv = *a.st;
+        const DecState sv = a.st[brow];
         tok = sv.cur_tok; tstep = sv.t; pos = sv.pos;
         if (a.epi == EPI_LMHEAD) skip = sv.suppress_eos ? 1 : -1;      // eos = 1 (meshanything.py:103)
         if (a.epi == EPI_EMBED) {
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                 const int n = blockIdx.x * RPB + r;
                 if (n < N && n != skip && arg_better(lv[r], n, bvv, bi)) { bvv = lv[r]; bi = n; }
             }
-            a.part_val[blockIdx.x] = bvv; a.part_idx[blockIdx.x] = bi;
+            a.part_val[(size_t)brow * a.part_stride + blockIdx.x] = bvv; a.part_idx[(size_t)brow * a.part_stride + blockIdx.x] = bi;
         }
     } else if (fin) {
         if (a.epi == EPI_EMBED) {
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                 if (part == 0) a.y[c] = v;
                 else {
                     const int head = c >> 6, d = c & 63;
-                    const size_t off = ((size_t)head * a.max_seq + pos) * 64 + d;
+                    const size_t off = (size_t)brow * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
                     store_kv<WT>(reinterpret_cast<WT*>(part == 1 ? a.kcache : a.vcache) + off, v);
                 }
             } else {
@@ -352,7 +362,7 @@ inline void launch_gemv_pro(const GemvArgs& a, int pro, dim3 grid, hipStream_t s
 }
 
 template <typename WT>
-inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
+inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s, int batch = 1) {
     constexpr int VEC = WTraits<WT>::VEC;
     if (a.K % VEC != 0) return hipErrorInvalidValue;
     const int pro = a.attn_ws ? PRO_ATTN : (a.ln_g ? PRO_LN : PRO_PLAIN);
@@ -360,7 +370,7 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s) {
     GemvShape g = gemv_shape<WT>(a.N, a.K);
     if (pro == PRO_ATTN && g.lpl > 0 && a.K > 1024) g = GemvShape{1, 0, 1};       // wide merges take the generic path
     const int rpb = (4 / g.ksplit) * g.rpw;
-    const dim3 grid((a.N + rpb - 1) / rpb);
+    const dim3 grid((a.N + rpb - 1) / rpb, batch);
 #define MA_GEMV_CASE(KS, LP, RW) if (g.ksplit == KS && g.lpl == LP && g.rpw == RW) { launch_gemv_pro<WT, KS, LP, RW>(a, pro, grid, s); return hipGetLastError(); }
     MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
     MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)

@@ -139,9 +139,15 @@ __device__ inline float hash_uniform(unsigned long long seed, int row, int t) {
 
 constexpr int PICK_KMAX = 64;
 
+// grid = batch rows: block b owns row b's logits, partials, state record and output row (nothing is shared between blocks).
 __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ logits, int V, const float* __restrict__ part_val,
-                                                   const int* __restrict__ part_idx, int nparts, DecState* st,
-                                                   long long* __restrict__ tokens_out, int T) {
+                                                   const int* __restrict__ part_idx, int nparts, int part_stride, DecState* st,
+                                                   long long* __restrict__ tokens_out, int tokens_stride, int T) {
+    logits += (size_t)blockIdx.x * V;
+    part_val += (size_t)blockIdx.x * part_stride;
+    part_idx += (size_t)blockIdx.x * part_stride;
+    st += blockIdx.x;
+    tokens_out += (size_t)blockIdx.x * tokens_stride;
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // V floats (sampling only)
     __shared__ float rv[4]; __shared__ int ri[4];
     __shared__ float cv[PICK_KMAX]; __shared__ int ci[PICK_KMAX];
@@ -215,9 +221,20 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     }
 }
 
-__global__ void init_state_kernel(DecState* st, DecState v) { *st = v; }
-// used by stepwise prefill / profiling: set the fields one decode step reads
-__global__ void set_pos_kernel(DecState* st, int t, int pos, int cur_tok) { st->t = t; st->pos = pos; st->cur_tok = cur_tok; }
+// one state record per batch row; rows differ in `row` and in their slice of the injected uniforms
+__global__ void init_state_kernel(DecState* st, DecState v, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    v.row += b;
+    if (v.uniforms) v.uniforms += (size_t)b * v.max_new;
+    st[b] = v;
+}
+// used by stepwise prefill / profiling: set the fields one decode step reads (all rows)
+__global__ void set_pos_kernel(DecState* st, int t, int pos, int cur_tok, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    st[b].t = t; st[b].pos = pos; st[b].cur_tok = cur_tok;
+}
 __global__ void fill_tokens_kernel(long long* p, long long v, int n) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) p[idx] = v;

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 {
   echo "== kernels"; timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider --tb=short -x 2>&1 | tail -25
-  echo "== pipeline tiny"; timeout 900 python -m pytest tests/test_gpu_pipeline.py -m gpu -q --no-header -p no:cacheprovider --tb=short -k "tiny or weights" -x 2>&1 | tail -25
+  echo "== pipeline tiny"; timeout 900 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_model_api.py -m gpu -q --no-header -p no:cacheprovider --tb=short -k "not full" -x 2>&1 | tail -40
 } > gpurun_out/quick_check.log 2>&1
 tail -c 3000 gpurun_out/quick_check.log
 echo "== step timing"

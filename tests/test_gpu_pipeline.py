@@ -112,6 +112,32 @@ def test_generate_eos_and_padding_semantics(tiny):
         assert toks.shape == ref.shape
 
 
+def test_batched_rows_equal_single_row_runs(tiny):
+    """Rows of a batch step together and share the weight stream, but each row's arithmetic is its own: a batch of 4 must
+    produce, row for row, exactly the tokens of four batch-1 generations (greedy and sampled, with and without eos)."""
+    x = clouds(tiny.cfg, [30, 31, 32, 33])
+    prefix = tiny.oracle.process_point_feature(tiny.oracle.encode_latents(x)).cuda()
+    for kw in (dict(suppress_eos=True), dict(), dict(sampling=True, seed=7, suppress_eos=True)):
+        toks, lengths = tiny.engine.generate(prefix, check_every=3, **kw)
+        for b in range(4):
+            if kw.get("sampling"):
+                continue                                       # the hashed uniform stream is keyed by the row index
+            one, l1 = tiny.engine.generate(prefix[b:b + 1], check_every=3, **kw)
+            n = int(l1[0])
+            assert int(lengths[b]) == n
+            assert torch.equal(toks[b, :n], one[0, :n]), f"row {b} of the batch differs from its batch-1 run ({kw})"
+            assert (toks[b, n:] == 2).all()
+        again, _ = tiny.engine.generate(prefix, check_every=3, **kw)
+        assert torch.equal(toks, again)
+    # injected uniforms: row b reads its own slice, so a batched sampled run equals the per-row runs
+    g = torch.Generator().manual_seed(99)
+    u = torch.rand(4, tiny.cfg.max_new_tokens, generator=g)
+    toks, _ = tiny.engine.generate(prefix, sampling=True, uniforms=u, suppress_eos=True)
+    for b in range(4):
+        one, _ = tiny.engine.generate(prefix[b:b + 1], sampling=True, uniforms=u[b:b + 1], suppress_eos=True)
+        assert torch.equal(toks[b], one[0])
+
+
 def test_graph_eager_and_stepwise_prefill_agree(tiny):
     x = clouds(tiny.cfg, [10])
     prefix = tiny.oracle.process_point_feature(tiny.oracle.encode_latents(x)).cuda()
