@@ -22,6 +22,7 @@
 #include "attn_decode.hpp"
 #include "common.hpp"
 #include "gemm.hpp"
+#include "gemm_decode.hpp"
 #include "gemv.hpp"
 #include "misc.hpp"
 #include "state.hpp"
@@ -97,6 +98,8 @@ struct ma_engine {
     int opt_gemm_impl = 0;           // 0 MFMA, 1 VALU reference kernel
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
+    int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
+    bf16_t *d_xb = nullptr, *d_ffb = nullptr;      // bf16 activations of the batched path: [max_batch][hidden], [max_batch][ffn]
 
     template <typename Tp> Tp* dmalloc(size_t n) {
         void* p = nullptr;
@@ -253,8 +256,71 @@ void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s, int B) {
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
 }
 
+bool use_mfma_decode(ma_engine* e, int B) { return e->bf16 && B >= e->opt_mfma_min_batch && B <= 64 && e->cfg.hidden % 128 == 0 && e->cfg.ffn % 128 == 0 && e->cfg.hidden <= 1024; }
+
+void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, const float* x, const float* g, const float* b, float* xn_out, StepTimer& tm) {
+    if (!tm.on(0)) return;
+    const ma_config& c = e->cfg;
+    RowsProArgs a{};
+    a.x = x; a.x_stride = c.hidden; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
+    a.attn_ws = e->d_part + (size_t)rw.r0 * attn_workspace_floats(c.heads); a.attn_ws_stride = attn_workspace_floats(c.heads); a.attn_heads = c.heads;
+    a.xn_out = xn_out; a.xn_stride = c.hidden; a.xb = e->d_xb + (size_t)rw.r0 * c.hidden; a.xb_stride = c.hidden; a.K = c.hidden;
+    hipError_t r = launch_rows_prologue(a, pro, rw.B, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_prologue launch failed: ") + hipGetErrorString(r));
+}
+void gemm_dec(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
+    if (!tm.on(0)) return;
+    hipError_t r = launch_gemm_dec(a, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec launch failed: ") + hipGetErrorString(r));
+}
+
+// one OPT layer of one decode step for a batch on the matrix cores (gemm_decode.hpp): same data flow as enqueue_layer,
+// prologues as their own one-block-per-row launches
+void enqueue_layer_mfma(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden, B = rw.B;
+    const size_t r0 = rw.r0;
+    const DecLayerPtrs& w = e->dl[l];
+    float* h0 = e->d_h0 + r0 * H; float* q = e->d_q + r0 * H; float* y1 = e->d_ypre1 + r0 * H; float* y2 = e->d_ypre2 + r0 * H;
+    float* h1 = e->d_h1 + r0 * H; float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
+    bf16_t* xb = e->d_xb + r0 * H; bf16_t* ffb = e->d_ffb + r0 * c.ffn;
+    const float* resid = ln_g ? h0 : x_in;
+    const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
+    rows_prologue(e, s, ln_g ? PRO_LN : PRO_PLAIN, rw, x_in, ln_g, ln_b, ln_g ? h0 : nullptr, tm);
+    {
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B;
+        a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
+        gemm_dec(e, s, a, tm);
+    }
+    if (tm.on(1)) {
+        hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+    }
+    rows_prologue(e, s, PRO_ATTN, rw, nullptr, nullptr, nullptr, nullptr, tm);
+    {
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.bias = w.o_b; a.xb = xb; a.xb_stride = H; a.res = resid; a.res_stride = H; a.y = y1; a.y_stride = H;
+        a.N = H; a.K = H; a.B = B;
+        gemm_dec(e, s, a, tm);
+    }
+    rows_prologue(e, s, PRO_LN, rw, y1, w.ln1_g, w.ln1_b, h1, tm);
+    {
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(w.fc1_w); a.bias = w.fc1_b; a.xb = xb; a.xb_stride = H; a.yb = ffb; a.yb_stride = c.ffn; a.N = c.ffn; a.K = H; a.B = B; a.act = ACT_RELU;
+        gemm_dec(e, s, a, tm);
+    }
+    {
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(w.fc2_w); a.bias = w.fc2_b; a.xb = ffb; a.xb_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H;
+        a.N = H; a.K = c.ffn; a.B = B;
+        gemm_dec(e, s, a, tm);
+    }
+}
+
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
 void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
+    if (use_mfma_decode(e, rw.B)) { enqueue_layer_mfma(e, s, l, x_in, ln_g, ln_b, len_override, tm, rw); return; }
     const ma_config& c = e->cfg;
     const int H = c.hidden, B = rw.B;
     const size_t r0 = rw.r0;
@@ -301,6 +367,14 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
 }
 
 void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw) {
+    if (use_mfma_decode(e, rw.B) && x_stride == e->cfg.hidden) {
+        rows_prologue(e, s, ln_g ? PRO_LN : PRO_PLAIN, rw, x, ln_g, ln_b, nullptr, tm);
+        GemmDecArgs g{};
+        g.W = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); g.xb = e->d_xb + (size_t)rw.r0 * e->cfg.hidden; g.xb_stride = e->cfg.hidden;
+        g.y = e->d_logits + (size_t)rw.r0 * e->V; g.y_stride = e->V; g.N = e->V; g.K = e->cfg.hidden; g.B = rw.B;
+        gemm_dec(e, s, g, tm);
+        return;
+    }
     GemvArgs a = gemv_base(e, rw);
     a.W = e->P("transformer.lm_head.weight"); a.x = x; a.x_stride = x_stride; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
     a.y = e->d_logits + (size_t)rw.r0 * e->V; a.y_stride = e->V; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD;
@@ -312,7 +386,7 @@ void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, 
 void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm, Rows rw) {
     if (!tm.on(3)) return;
     hipLaunchKernelGGL(pick_kernel, dim3(rw.B), dim3(256), (size_t)e->V * sizeof(float), s, e->d_logits + (size_t)rw.r0 * e->V, e->V,
-                       e->d_pval + (size_t)rw.r0 * e->V, e->d_pidx + (size_t)rw.r0 * e->V, e->n_parts, e->V, e->d_st + rw.r0,
+                       e->d_pval + (size_t)rw.r0 * e->V, e->d_pidx + (size_t)rw.r0 * e->V, use_mfma_decode(e, rw.B) ? 0 : e->n_parts, e->V, e->d_st + rw.r0,
                        e->w_tokens + (size_t)rw.r0 * e->maxnew, e->maxnew, e->T);
     HIP_CHECK(hipGetLastError());
 }
@@ -568,6 +642,7 @@ void build_engine(ma_engine* e) {
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
+    e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     HIP_CHECK(hipMemset(e->d_st, 0, MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));
@@ -668,6 +743,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "prefill_stepwise") e->opt_prefill_stepwise = (int)value;
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
+        else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "gemv_rpw") {
             if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1 or 2");
             gemv_rpw_big() = (int)value;

@@ -1,0 +1,209 @@
+// Batched decode step: the weight-streaming "GEMV" when B > 1 rows step together -- a skinny GEMM
+// Y[B,N] = epilogue(X[B,K] . W[N,K]^T) on the bf16 matrix cores (same reference call sites as gemv.hpp).
+//
+// The operand that matters is still W (2-16 MB per launch, read once from HBM whatever B is); X is B x K bf16 (<= 512 KB)
+// and lives in L2.  v_mfma_f32_16x16x32_bf16 with A = a 16-row tile of W (lane: row = lane & 15, 8 consecutive k at
+// (lane >> 4) * 8 -- exactly one 16-byte load from the row-major weight matrix, no LDS staging, no transpose) and
+// B = 16 batch rows of X (same lane -> k mapping, one 16-byte load from the bf16 activation buffer).  D[m][n]: lane holds
+// weight rows (lane >> 4) * 4 + r of batch row lane & 15, i.e. four consecutive outputs of one activation row -> one
+// 16-byte store.  One block = 16 weight rows; its 4 waves split K (each streams 16 x K/4 weights, 8 loads in flight per
+// lane and chunk) and meet once in LDS (fixed summation order: deterministic).  grid = N / 16 blocks.
+//
+// The prologues that the batch-1 GEMV runs per block (LayerNorm of the post-LN residual stream, merge of the split-KV
+// attention partials) would be repeated per block for every batch row here, so they run once per row in
+// `rows_prologue_kernel` (same arithmetic, same summation order as gemv.hpp) and hand the GEMM a bf16 activation buffer.
+// fp32 "exact" policy: no MFMA path; the engine uses the row-parallel GEMV (grid.y = batch row) instead.
+#pragma once
+#include "attn_decode.hpp"
+#include "common.hpp"
+#include "gemm.hpp"
+#include "gemv.hpp"
+#include "state.hpp"
+
+namespace ma {
+
+struct GemmDecArgs {
+    const bf16_t* W;            // [N][K] bf16
+    const float* bias;          // [N] or null
+    const bf16_t* xb; int xb_stride;     // activations [B][K] bf16 (already rounded by their producer)
+    const float* res; int res_stride;    // residual [B][N] fp32 or null
+    float* y; int y_stride;              // fp32 output [B][N] or null
+    bf16_t* yb; int yb_stride;           // bf16 output [B][N] or null (feeds the next GEMM directly)
+    int N, K, B, act, epi;               // epi: EPI_PLAIN | EPI_QKV
+    void* kcache; void* vcache; size_t kv_row_stride; int H; int max_seq;
+    const DecState* st;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int K = a.K, Kq = K >> 2;
+    const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + w * Kq + kg * 8;
+    const bf16_t* xrow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) xrow[t] = a.xb + (size_t)min(t * 16 + m, a.B - 1) * a.xb_stride + w * Kq + kg * 8;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int CH = 8;                                 // k-steps (32 k each) per chunk: 8 weight loads in flight per lane
+    for (int k0 = 0; k0 < Kq; k0 += CH * 32) {
+        u32x4 wv[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) wv[s] = (k0 + s * 32 < Kq) ? ld_stream16(wrow + k0 + s * 32) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (k0 + s * 32 < Kq) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const u32x4 xv = *reinterpret_cast<const u32x4*>(xrow[t] + k0 + s * 32);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv), acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&red[w][t][lane][0]) = acc[t];
+    __syncthreads();
+    // epilogue: wave t finishes batch tile t (tiles beyond the four waves do not exist: MT <= 4)
+    if (w >= MT) return;
+    const int t = w;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][t][lane][0]);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][t][lane][0]);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int b = t * 16 + m;                             // batch row of this lane
+    if (b >= a.B) return;
+    const int r0 = n0 + kg * 4;                           // first of this lane's four consecutive output rows
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const int pos = a.epi == EPI_QKV ? a.st[b].pos : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = r0 + r;
+        if (n >= a.N) continue;
+        float x = o[r];
+        if (a.bias) x += a.bias[n];
+        x = apply_act(x, a.act);
+        if (a.res) x += a.res[(size_t)b * a.res_stride + n];
+        if (a.epi == EPI_QKV) {
+            const int part = n / a.H, c = n - part * a.H;
+            if (part == 0) a.y[(size_t)b * a.y_stride + c] = x;
+            else {
+                const int head = c >> 6, d = c & 63;
+                const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
+                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = f2bf(x);
+            }
+        } else {
+            if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
+            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = f2bf(x);
+        }
+    }
+}
+
+inline hipError_t launch_gemm_dec(const GemmDecArgs& a, hipStream_t s) {
+    if (a.K % 128 != 0 || a.B < 1 || a.B > 64) return hipErrorInvalidValue;
+    const dim3 grid((a.N + 15) / 16), block(256);
+    const int mt = (a.B + 15) / 16;
+    if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1>), grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2>), grid, block, 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_dec_kernel<4>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- per-row prologue: one block per batch row --------------------------------------------------------------------------
+struct RowsProArgs {
+    const float* x; int x_stride;        // [B][K] fp32 (PRO_PLAIN / PRO_LN)
+    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* attn_ws; size_t attn_ws_stride; int attn_heads;      // PRO_ATTN: K = heads * 64
+    float* xn_out; int xn_stride;        // prologue(x) fp32 (the residual of a later epilogue) or null
+    bf16_t* xb; int xb_stride;           // prologue(x) rounded to bf16: the GEMM's activation operand
+    int K;
+};
+
+// thread t owns the float4 chunks t, t+256, ... of its row: the same partition, arithmetic and summation order as the
+// block-level prologue of gemv_kernel, so a batched row sees the same activation bits as a batch-1 run
+template <int PRO>
+__global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x, K = a.K;
+    constexpr int NCH = 4;                               // K <= 4096
+    f32x4 xv[NCH];
+    const int nq = K / 4;
+    if constexpr (PRO == PRO_ATTN) {
+        const int k = tid * 4;
+        if (k < K) {
+            f32x4 pml[ATTN_NCHUNK / 2], po[ATTN_NCHUNK];
+            attn_partials_load(a.attn_ws + (size_t)b * a.attn_ws_stride, a.attn_heads, k >> 6, k & 63, pml, po);
+            xv[0] = attn_partials_merge(pml, po);
+        }
+    } else {
+        const float* x = a.x + (size_t)b * a.x_stride;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 256 * j;
+            xv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(x + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if constexpr (PRO == PRO_LN) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        s = wave_sum(s);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (tid + 256 * j < nq) {
+                const float d0 = xv[j].x - mean, d1 = xv[j].y - mean, d2 = xv[j].z - mean, d3 = xv[j].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + w] = q;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)K + a.ln_eps);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < nq) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + idx * 4);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.ln_b + idx * 4);
+                xv[j].x = (xv[j].x - mean) * rstd * g.x + bb.x;
+                xv[j].y = (xv[j].y - mean) * rstd * g.y + bb.y;
+                xv[j].z = (xv[j].z - mean) * rstd * g.z + bb.z;
+                xv[j].w = (xv[j].w - mean) * rstd * g.w + bb.w;
+            }
+        }
+    }
+    constexpr int NJ = PRO == PRO_ATTN ? 1 : NCH;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < nq) {
+            if (a.xn_out) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)b * a.xn_stride + idx * 4) = xv[j];
+            u32x2 pk;
+            pk.x = (uint32_t)f2bf(xv[j].x) | ((uint32_t)f2bf(xv[j].y) << 16);
+            pk.y = (uint32_t)f2bf(xv[j].z) | ((uint32_t)f2bf(xv[j].w) << 16);
+            *reinterpret_cast<u32x2*>(a.xb + (size_t)b * a.xb_stride + idx * 4) = pk;
+        }
+    }
+}
+
+inline hipError_t launch_rows_prologue(const RowsProArgs& a, int pro, int B, hipStream_t s) {
+    if (a.K % 4 != 0 || a.K > 4096 || (pro == PRO_ATTN && (a.K > 1024 || a.K != a.attn_heads * 64))) return hipErrorInvalidValue;
+    if (pro == PRO_LN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_LN>), dim3(B), dim3(256), 0, s, a);
+    else if (pro == PRO_ATTN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_ATTN>), dim3(B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rows_prologue_kernel<PRO_PLAIN>), dim3(B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ma

@@ -156,7 +156,12 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     const int do_sample = st->do_sample;
     if (!do_sample) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+        if (nparts > 0) {            // per-block partials of the lm_head GEMV (eos already excluded there when suppressed)
+            for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+        } else {                     // batched MFMA lm_head: plain logits
+            const int skip = st->suppress_eos ? TOK_EOS : -1;
+            for (int i = tid; i < V; i += 256) { const float v = logits[i]; if (i != skip && arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);

@@ -502,6 +502,27 @@ def verify_sampled_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Te
             c = np.concatenate([[0.0], np.cumsum(probs.double().numpy())])
             i = kl.index(tok)
             ok = (c[i] - tol) <= float(uniforms[j]) <= (c[i + 1] + tol)
+        if not ok:
+            # The kept SET can differ by one token when the ascending cumulative mass at the top-p cut sits within `tol`
+            # of 1 - top_p: re-draw with one token more / fewer kept, but only if that boundary really is that close.
+            V = lg.shape[0]
+            order = sorted(range(V), key=lambda q: (-float(lg[q]), q))[:min(50, V)]
+            pk = torch.softmax(lg[order].double(), dim=0).numpy()                # over the top-k candidates, descending
+            tail = np.cumsum(pk[::-1])[::-1]                                     # tail[r] = mass of candidates ranked r..last
+            nkept = len(kl)
+            for nk in (nkept - 1, nkept + 1):
+                if nk < 1 or nk > len(order) or tok not in order[:nk]:
+                    continue
+                r = nkept if nk > nkept else nkept - 1                           # rank of the token that changes sides
+                if abs(float(tail[r]) - 0.05) > tol:
+                    continue
+                alt = order[:nk]
+                pa = torch.softmax(lg[alt].double(), dim=0).numpy()
+                c = np.concatenate([[0.0], np.cumsum(pa)])
+                i = alt.index(tok)
+                if (c[i] - tol) <= float(uniforms[j]) <= (c[i + 1] + tol):
+                    ok = True
+                    break
         if ok:
             ambiguous += 1
         else:

@@ -13,12 +13,14 @@ ap.add_argument("--gen", type=int, default=0, help="also generate this many toke
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--options", default="gemv_rpw=1;gemv_rpw=2")
 ap.add_argument("--faces", type=int, default=800)
+ap.add_argument("--batch", type=int, default=1)
 a = ap.parse_args()
-cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, n_max_faces=a.faces)
+cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, n_max_faces=a.faces, max_batch=a.batch)
 eng = Engine(cfg)
 t0 = time.time()
 eng.load_weights(synthetic_items(cfg))
 print(f"weights loaded in {time.time()-t0:.1f}s", flush=True)
+eng.set_option("profile_batch", a.batch)
 lens = [300, 1000, 3800, cfg.max_seq - 3 * a.steps - 16]
 for opt in a.options.split(";"):
     for kv in opt.split(","):
@@ -29,7 +31,7 @@ for opt in a.options.split(";"):
         eng.profile_decode(L, 2)                      # warm (graph capture, clocks)
         p = eng.profile_decode(L, a.steps)
         per = {k: round(v / a.steps * 1e3, 1) for k, v in p["ms"].items() if p["launches"][k]}
-        print(f"[{opt}] len {L:5d}: step graph {p['step_ms_graph']*1e3:7.1f} us  eager {p['step_ms_eager']*1e3:7.1f} us  per-class(us, event-bracketed eager) {per}", flush=True)
+        print(f"[B={a.batch} {opt}] len {L:5d}: step graph {p['step_ms_graph']*1e3:7.1f} us  eager {p['step_ms_eager']*1e3:7.1f} us  per-class(us, event-bracketed eager) {per}", flush=True)
 if a.gen:
     d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dataset.npz"))
     x = torch.from_numpy(d["mouse_norm"])[None].cuda()
