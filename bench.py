@@ -55,7 +55,7 @@ def kv_bytes_per_step(cfg: MAConfig, length: int, esz: int) -> int:
     return cfg.layers * 2 * cfg.hidden * esz * length
 
 
-def cpu_baseline(cfg: MAConfig, sd, x: torch.Tensor, decode_steps: int = 32):
+def cpu_baseline(cfg: MAConfig, sd, x: torch.Tensor, decode_steps: int = 384):
     """The oracle (a CPU port of the reference arithmetic, fp32, PyTorch threads = host cores) on a bounded sample of the
     same workload: encode + prefill + `decode_steps` greedy KV-cache steps for the same cloud and weights."""
     from oracle.meshanything_oracle import Oracle
@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--faces", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1, help="shapes per GPU decoded together (BASELINE.json configs 3-5 use 64 / 8)")
+    ap.add_argument("--sampling", action="store_true", help="top-k 50 / top-p 0.95 sampling (configs 3-4) instead of greedy")
+    ap.add_argument("--no-batched-table", action="store_true", help="skip the batch 8 / 64 decode-step table of the default run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +117,7 @@ def main():
 
     from meshanything_amd.engine import Engine
     from meshanything_amd import dp
-    cfg = MAConfig.full(dtype=DTYPE_BF16 if args.dtype == "bf16" else DTYPE_F32, n_max_faces=args.faces, max_batch=1)
+    cfg = MAConfig.full(dtype=DTYPE_BF16 if args.dtype == "bf16" else DTYPE_F32, n_max_faces=args.faces, max_batch=args.batch)
     eng = Engine(cfg, local_rank)
     sd = {}
     t_load = time.time()
@@ -126,15 +129,20 @@ def main():
     dp.load_weights_dp(eng, items, rank, world)
     t_load = time.time() - t_load
 
-    if rank == 0:
-        d = np.load(os.path.join(REPO, "tests", "golden", "dataset.npz"))
-        pc = d["mouse_norm"]                                # pc_examples/mouse.npy after Dataset normalisation (seed 0)
-    else:
-        pc = normalize_pc(synth_cloud(rank, cfg.n_points))
-    x = torch.from_numpy(pc)[None].cuda()
+    # shapes of this rank: global shape index g = rank * batch + j; shape 0 is pc_examples/mouse.npy after Dataset
+    # normalisation (seed 0), every other one a seeded synthetic cloud
+    rows = []
+    for j in range(args.batch):
+        gidx = rank * args.batch + j
+        if gidx == 0:
+            rows.append(np.load(os.path.join(REPO, "tests", "golden", "dataset.npz"))["mouse_norm"])
+        else:
+            rows.append(normalize_pc(synth_cloud(gidx, cfg.n_points)))
+    pc = np.stack(rows)
+    x = torch.from_numpy(pc).cuda()
 
     def step():
-        return eng.forward(x, suppress_eos=True)
+        return eng.forward(x, suppress_eos=True, sampling=args.sampling, seed=1234)
 
     for _ in range(args.warmup):
         out = step()
@@ -152,8 +160,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    tokens_per_step = cfg.max_new_tokens
-    assert out["tokens"].shape[1] == tokens_per_step
+    tokens_per_step = cfg.max_new_tokens * args.batch
+    assert tuple(out["tokens"].shape) == (args.batch, cfg.max_new_tokens)
 
     if rank == 0:
         esz = 2 if args.dtype == "bf16" else 4
@@ -162,7 +170,7 @@ def main():
         ev[0].record()
         lat, prefix = eng.encode(x)
         ev[1].record()
-        toks, _ = eng.generate(prefix, suppress_eos=True)
+        toks, _ = eng.generate(prefix, suppress_eos=True, sampling=args.sampling, seed=1234)
         ev[2].record()
         ids = eng.postprocess_tokens(toks)
         coords = eng.detokenize(ids, lat)
@@ -174,6 +182,7 @@ def main():
         # boundary to the next launch included -- the number a rocprofv3 kernel trace of the same command reports
         # (profiles/).  Algorithmic bytes per launch = weight bytes of one step / GEMV launches of one step.
         mid = cfg.cond_length + cfg.max_new_tokens // 2
+        eng.set_option("profile_batch", args.batch)
         prof = eng.profile_decode(mid, args.profile_steps)
         wbytes, launches = gemv_bytes_per_step(cfg, esz)
         n_l = prof["launches"]["gemv"]
@@ -182,29 +191,58 @@ def main():
         bytes_per_launch = wbytes / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         step_ms = prof["step_ms_graph"] or prof["step_ms_eager"]
-        step_bytes = wbytes + kv_bytes_per_step(cfg, mid, esz)
+        step_bytes = wbytes + args.batch * kv_bytes_per_step(cfg, mid, esz)
         attn_ms = prof["ms"]["attn_decode"] / max(1, prof["launches"]["attn_decode"])
+        # HBM bytes per GEMV launch from the PMC counters (collected by scripts/gpu_pmc.sh in separate rocprofv3 --pmc passes and
+        # corrected as the MI355X guide prescribes; committed under profiles/): None when no such file is present
+        traffic = None
+        import glob
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_gemv_traffic.json"))):
+            if args.batch == 1 and args.dtype == "bf16" and args.faces == 800:
+                traffic = int(json.load(open(f))["hbm_bytes_per_launch"])
         roofline = {"bound": "hbm", "kernel": "gemv_kernel (decode weight stream, 98 launches per step)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": n_l,
                     "decode_step_ms_graph": round(prof["step_ms_graph"], 4), "decode_step_ms_eager": round(prof["step_ms_eager"], 4),
                     "decode_step_GBps_at_mid_context": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
                     "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "attn_decode": {"kv_len": mid, "avg_launch_us": round(attn_ms * 1e3, 3),
-                                    "GBps": round(kv_bytes_per_step(cfg, mid, esz) / cfg.layers / (attn_ms * 1e-3) / 1e9, 1)}}
+                                    "GBps": round(args.batch * kv_bytes_per_step(cfg, mid, esz) / cfg.layers / (attn_ms * 1e-3) / 1e9, 1)}}
+        if args.batch > 1 and args.dtype == "bf16" and args.batch >= 4:
+            roofline["kernel"] = "gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream: 98 skinny GEMMs + 73 prologues per step)"
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc)[None])
+            cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))
+        batched = None
+        if args.batch == 1 and not args.no_batched_table and args.dtype == "bf16":
+            # configs 3-5 in brief: the decode step when 8 / 64 shapes share the weight stream (mid context, graph replay)
+            eng.close()
+            torch.cuda.empty_cache()
+            cfg_b = MAConfig.full(dtype=DTYPE_BF16, n_max_faces=args.faces, max_batch=64)
+            eng_b = Engine(cfg_b, local_rank)
+            eng_b.load_weights(sd.items())
+            batched = []
+            for Bb in (8, 64):
+                eng_b.set_option("profile_batch", Bb)
+                pb = eng_b.profile_decode(mid, 2)
+                sb = pb["step_ms_graph"]
+                byts = wbytes + Bb * kv_bytes_per_step(cfg_b, mid, 2)
+                batched.append({"batch": Bb, "kv_len": mid, "decode_step_ms": round(sb, 4), "face_tokens_per_s": round(Bb / (sb * 1e-3), 1),
+                                "GBps": round(byts / (sb * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(byts / (sb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            eng_b.close()
         total_tokens = world * args.steps * tokens_per_step
         res = {
-            "metric": "face-tokens/sec (800-face cap, batch 1 per GPU) + sec/mesh", "value": round(total_tokens / dt, 2), "unit": "face-tokens/s",
+            "metric": f"face-tokens/sec ({args.faces}-face cap, batch {args.batch} per GPU) + sec/mesh", "value": round(total_tokens / dt, 2), "unit": "face-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: single shape pc_examples/mouse.npy (Dataset-normalised, seed 0), 350M shape, "
-                                   f"{args.dtype}, 1xMI355X per rank, greedy, {args.faces}-face cap ({tokens_per_step} tokens, eos suppressed), KV-cache decode, hipGraph",
-                       "global_batch": world, "tokens_per_mesh": tokens_per_step, "parallelism": f"dp{world} (independent shapes, weights broadcast once)",
+            "config": {"workload": (f"BASELINE.json configs[{1 if args.batch == 1 else (3 if args.faces == 800 else 4)}]: "
+                                    + ("single shape pc_examples/mouse.npy (Dataset-normalised, seed 0)" if args.batch == 1
+                                       else f"batch {args.batch} per GPU (mouse.npy + seeded synthetic 4096-pt clouds)")
+                                    + f", 350M shape, {args.dtype}, 1xMI355X per rank, {'top-k 50 / top-p 0.95 sampling' if args.sampling else 'greedy'}, "
+                                      f"{args.faces}-face cap ({cfg.max_new_tokens} tokens/shape, eos suppressed), KV-cache decode, hipGraph"),
+                       "global_batch": world * args.batch, "tokens_per_mesh": cfg.max_new_tokens, "parallelism": f"dp{world} (independent shapes, weights broadcast once)",
                        "weights": "seeded random init in the reference key layout (no checkpoint available offline)"},
-            "sec_per_mesh": round(dt / args.steps, 4), "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+            "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
             "weights_load_s": round(t_load, 2), "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
