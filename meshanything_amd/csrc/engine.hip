@@ -100,6 +100,7 @@ struct ma_engine {
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     bf16_t *d_xb = nullptr, *d_ffb = nullptr;      // bf16 activations of the batched path: [max_batch][hidden], [max_batch][ffn]
+    float *d_ks_o = nullptr, *d_ks_f = nullptr;    // split-K partials of out_proj / fc2: [4][max_batch][hidden]
 
     template <typename Tp> Tp* dmalloc(size_t n) {
         void* p = nullptr;
@@ -258,11 +259,15 @@ void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s, int B) {
 
 bool use_mfma_decode(ma_engine* e, int B) { return e->bf16 && B >= e->opt_mfma_min_batch && B <= 64 && e->cfg.hidden % 128 == 0 && e->cfg.ffn % 128 == 0 && e->cfg.hidden <= 1024; }
 
-void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, const float* x, const float* g, const float* b, float* xn_out, StepTimer& tm) {
+// input of a batched prologue: either a plain fp32 buffer, or the raw partials of a split-K GEMM plus its deferred epilogue
+struct ProIn { const float* x = nullptr; int nparts = 1; const float* bias = nullptr; const float* res = nullptr; };
+
+void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, ProIn in, const float* g, const float* b, float* xn_out, StepTimer& tm) {
     if (!tm.on(0)) return;
     const ma_config& c = e->cfg;
     RowsProArgs a{};
-    a.x = x; a.x_stride = c.hidden; a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
+    a.x = in.x; a.x_stride = c.hidden; a.nparts = in.nparts; a.B = rw.B; a.bias = in.bias; a.res = in.res; a.res_stride = c.hidden;
+    a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
     a.attn_ws = e->d_part + (size_t)rw.r0 * attn_workspace_floats(c.heads); a.attn_ws_stride = attn_workspace_floats(c.heads); a.attn_heads = c.heads;
     a.xn_out = xn_out; a.xn_stride = c.hidden; a.xb = e->d_xb + (size_t)rw.r0 * c.hidden; a.xb_stride = c.hidden; a.K = c.hidden;
     hipError_t r = launch_rows_prologue(a, pro, rw.B, s);
@@ -274,53 +279,82 @@ void gemm_dec(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) 
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec launch failed: ") + hipGetErrorString(r));
 }
 
-// one OPT layer of one decode step for a batch on the matrix cores (gemm_decode.hpp): same data flow as enqueue_layer,
-// prologues as their own one-block-per-row launches
-void enqueue_layer_mfma(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
+// The 24 OPT layers + lm_head of one decode step for a batch on the matrix cores (gemm_decode.hpp).  Same data flow as the
+// GEMV path; the prologues are one-block-per-row launches, and the two N = hidden GEMMs (out_proj, fc2) are split along K
+// with their bias / residual folded into the LayerNorm prologue that follows them.
+//   layer input:  l == 0: the embedding (plain);  l > 0: LN2_{l-1}(h1 + fc2 partials + b2)  -> h0 (fp32 residual), xb (bf16)
+void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int len_override, StepTimer& tm, Rows rw) {
     const ma_config& c = e->cfg;
-    const int H = c.hidden, B = rw.B;
-    const size_t r0 = rw.r0;
-    const DecLayerPtrs& w = e->dl[l];
-    float* h0 = e->d_h0 + r0 * H; float* q = e->d_q + r0 * H; float* y1 = e->d_ypre1 + r0 * H; float* y2 = e->d_ypre2 + r0 * H;
-    float* h1 = e->d_h1 + r0 * H; float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
+    const int H = c.hidden, B = rw.B, L = c.layers;
+    const size_t r0 = rw.r0, MB = c.max_batch;
+    float* h0 = e->d_h0 + r0 * H; float* q = e->d_q + r0 * H; float* h1 = e->d_h1 + r0 * H; float* y1 = e->d_ypre1 + r0 * H; float* y2 = e->d_ypre2 + r0 * H;
+    float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
     bf16_t* xb = e->d_xb + r0 * H; bf16_t* ffb = e->d_ffb + r0 * c.ffn;
-    const float* resid = ln_g ? h0 : x_in;
+    // split-K partial buffers [ks][B][H]; rows r0.. of a B-row call use the first B rows of each slab (one call at a time)
+    float* partO = e->d_ks_o; float* partF = e->d_ks_f;
+    (void)MB;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
-    rows_prologue(e, s, ln_g ? PRO_LN : PRO_PLAIN, rw, x_in, ln_g, ln_b, ln_g ? h0 : nullptr, tm);
-    {
-        GemmDecArgs a{};
-        a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B;
-        a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
-        gemm_dec(e, s, a, tm);
+    const int ks_o = gemm_dec_ksplit(H, H), ks_f = gemm_dec_ksplit(H, c.ffn);
+    for (int l = 0; l < L; ++l) {
+        const DecLayerPtrs& w = e->dl[l];
+        const float* resid;
+        if (l == 0) {
+            ProIn in; in.x = x_embed;
+            rows_prologue(e, s, PRO_PLAIN, rw, in, nullptr, nullptr, nullptr, tm);
+            resid = x_embed;
+        } else {
+            ProIn in;
+            if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[l - 1].fc2_b; in.res = h1; } else in.x = y2;
+            rows_prologue(e, s, PRO_LN, rw, in, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, h0, tm);
+            resid = h0;
+        }
+        {
+            GemmDecArgs a{};
+            a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1;
+            a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
+            gemm_dec(e, s, a, tm);
+        }
+        if (tm.on(1)) {
+            hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems);
+            if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+        }
+        rows_prologue(e, s, PRO_ATTN, rw, ProIn{}, nullptr, nullptr, nullptr, tm);
+        {   // y1 = resid + Wo a + bo
+            GemmDecArgs a{};
+            a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.xb = xb; a.xb_stride = H; a.N = H; a.K = H; a.B = B; a.ksplit = ks_o; a.y_stride = H;
+            if (ks_o > 1) a.y = partO; else { a.y = y1; a.bias = w.o_b; a.res = resid; a.res_stride = H; }
+            gemm_dec(e, s, a, tm);
+        }
+        {
+            ProIn in;
+            if (ks_o > 1) { in.x = partO; in.nparts = ks_o; in.bias = w.o_b; in.res = resid; } else in.x = y1;
+            rows_prologue(e, s, PRO_LN, rw, in, w.ln1_g, w.ln1_b, h1, tm);
+        }
+        {
+            GemmDecArgs a{};
+            a.W = reinterpret_cast<const bf16_t*>(w.fc1_w); a.bias = w.fc1_b; a.xb = xb; a.xb_stride = H; a.yb = ffb; a.yb_stride = c.ffn; a.N = c.ffn; a.K = H; a.B = B; a.ksplit = 1;
+            a.act = ACT_RELU;
+            gemm_dec(e, s, a, tm);
+        }
+        {   // y2 = h1 + W2 f + b2
+            GemmDecArgs a{};
+            a.W = reinterpret_cast<const bf16_t*>(w.fc2_w); a.xb = ffb; a.xb_stride = c.ffn; a.N = H; a.K = c.ffn; a.B = B; a.ksplit = ks_f; a.y_stride = H;
+            if (ks_f > 1) a.y = partF; else { a.y = y2; a.bias = w.fc2_b; a.res = h1; a.res_stride = H; }
+            gemm_dec(e, s, a, tm);
+        }
     }
-    if (tm.on(1)) {
-        hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems);
-        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
-    }
-    rows_prologue(e, s, PRO_ATTN, rw, nullptr, nullptr, nullptr, nullptr, tm);
-    {
-        GemmDecArgs a{};
-        a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.bias = w.o_b; a.xb = xb; a.xb_stride = H; a.res = resid; a.res_stride = H; a.y = y1; a.y_stride = H;
-        a.N = H; a.K = H; a.B = B;
-        gemm_dec(e, s, a, tm);
-    }
-    rows_prologue(e, s, PRO_LN, rw, y1, w.ln1_g, w.ln1_b, h1, tm);
-    {
-        GemmDecArgs a{};
-        a.W = reinterpret_cast<const bf16_t*>(w.fc1_w); a.bias = w.fc1_b; a.xb = xb; a.xb_stride = H; a.yb = ffb; a.yb_stride = c.ffn; a.N = c.ffn; a.K = H; a.B = B; a.act = ACT_RELU;
-        gemm_dec(e, s, a, tm);
-    }
-    {
-        GemmDecArgs a{};
-        a.W = reinterpret_cast<const bf16_t*>(w.fc2_w); a.bias = w.fc2_b; a.xb = ffb; a.xb_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H;
-        a.N = H; a.K = c.ffn; a.B = B;
-        gemm_dec(e, s, a, tm);
-    }
+    // lm_head on LN2_{L-1}(y2)
+    ProIn in;
+    if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[L - 1].fc2_b; in.res = h1; } else in.x = y2;
+    rows_prologue(e, s, PRO_LN, rw, in, e->dl[L - 1].ln2_g, e->dl[L - 1].ln2_b, nullptr, tm);
+    GemmDecArgs g{};
+    g.W = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); g.xb = xb; g.xb_stride = H;
+    g.y = e->d_logits + r0 * e->V; g.y_stride = e->V; g.N = e->V; g.K = H; g.B = B; g.ksplit = 1;
+    gemm_dec(e, s, g, tm);
 }
 
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
 void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
-    if (use_mfma_decode(e, rw.B)) { enqueue_layer_mfma(e, s, l, x_in, ln_g, ln_b, len_override, tm, rw); return; }
     const ma_config& c = e->cfg;
     const int H = c.hidden, B = rw.B;
     const size_t r0 = rw.r0;
@@ -367,14 +401,6 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
 }
 
 void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw) {
-    if (use_mfma_decode(e, rw.B) && x_stride == e->cfg.hidden) {
-        rows_prologue(e, s, ln_g ? PRO_LN : PRO_PLAIN, rw, x, ln_g, ln_b, nullptr, tm);
-        GemmDecArgs g{};
-        g.W = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); g.xb = e->d_xb + (size_t)rw.r0 * e->cfg.hidden; g.xb_stride = e->cfg.hidden;
-        g.y = e->d_logits + (size_t)rw.r0 * e->V; g.y_stride = e->V; g.N = e->V; g.K = e->cfg.hidden; g.B = rw.B;
-        gemm_dec(e, s, g, tm);
-        return;
-    }
     GemvArgs a = gemv_base(e, rw);
     a.W = e->P("transformer.lm_head.weight"); a.x = x; a.x_stride = x_stride; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
     a.y = e->d_logits + (size_t)rw.r0 * e->V; a.y_stride = e->V; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD;
@@ -406,12 +432,16 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, rw.B);
     }
-    const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
-    for (int l = 0; l < c.layers; ++l) {
-        if (l == 0) enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw);
-        else enqueue_layer(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm, rw);
+    if (use_mfma_decode(e, rw.B)) {
+        enqueue_layers_mfma(e, s, de, len_override, tm, rw);
+    } else {
+        const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
+        for (int l = 0; l < c.layers; ++l) {
+            if (l == 0) enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw);
+            else enqueue_layer(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm, rw);
+        }
+        enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw);
     }
-    enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw);
     enqueue_pick(e, s, tm, rw);
 }
 
@@ -643,6 +673,7 @@ void build_engine(ma_engine* e) {
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
+    e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
     HIP_CHECK(hipMemset(e->d_st, 0, MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));

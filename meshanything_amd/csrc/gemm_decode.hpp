@@ -7,7 +7,11 @@
 // B = 16 batch rows of X (same lane -> k mapping, one 16-byte load from the bf16 activation buffer).  D[m][n]: lane holds
 // weight rows (lane >> 4) * 4 + r of batch row lane & 15, i.e. four consecutive outputs of one activation row -> one
 // 16-byte store.  One block = 16 weight rows; its 4 waves split K (each streams 16 x K/4 weights, 8 loads in flight per
-// lane and chunk) and meet once in LDS (fixed summation order: deterministic).  grid = N / 16 blocks.
+// lane and chunk) and meet once in LDS (fixed summation order: deterministic).  grid = (N / 16, KS): matrices with few
+// rows (out_proj, fc2: N = 1024 -> 64 row tiles) are also split along K over KS blocks so that every CU streams; a split
+// launch writes raw fp32 partials [KS][B][N] and its bias / residual / LayerNorm happen in the next `rows_prologue_kernel`,
+// which sums the KS partials in fixed order first.  All loads of a chunk (weights AND activations) are issued before its
+// first MFMA.
 //
 // The prologues that the batch-1 GEMV runs per block (LayerNorm of the post-LN residual stream, merge of the split-KV
 // attention partials) would be repeated per block for every batch row here, so they run once per row in
@@ -27,49 +31,50 @@ struct GemmDecArgs {
     const float* bias;          // [N] or null
     const bf16_t* xb; int xb_stride;     // activations [B][K] bf16 (already rounded by their producer)
     const float* res; int res_stride;    // residual [B][N] fp32 or null
-    float* y; int y_stride;              // fp32 output [B][N] or null
+    float* y; int y_stride;              // fp32 output [B][N] or null; with ksplit > 1: partials [ksplit][B][y_stride] (raw sums)
     bf16_t* yb; int yb_stride;           // bf16 output [B][N] or null (feeds the next GEMM directly)
     int N, K, B, act, epi;               // epi: EPI_PLAIN | EPI_QKV
+    int ksplit;                          // grid.y: blocks along K (1 = whole K in one block, epilogue applied here)
     void* kcache; void* vcache; size_t kv_row_stride; int H; int max_seq;
     const DecState* st;
 };
 
-template <int MT>
+template <int MT, int CH>
 __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int K = a.K, Kq = K >> 2;
-    const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + w * Kq + kg * 8;
+    const int K = a.K, Kw = K / (4 * a.ksplit);            // k-range of one wave
+    const int kbase = (blockIdx.y * 4 + w) * Kw + kg * 8;
+    const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + kbase;
     const bf16_t* xrow[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) xrow[t] = a.xb + (size_t)min(t * 16 + m, a.B - 1) * a.xb_stride + w * Kq + kg * 8;
+    for (int t = 0; t < MT; ++t) xrow[t] = a.xb + (size_t)min(t * 16 + m, a.B - 1) * a.xb_stride + kbase;
 
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int CH = 8;                                 // k-steps (32 k each) per chunk: 8 weight loads in flight per lane
-    for (int k0 = 0; k0 < Kq; k0 += CH * 32) {
-        u32x4 wv[CH];
-#pragma unroll
-        for (int s = 0; s < CH; ++s) wv[s] = (k0 + s * 32 < Kq) ? ld_stream16(wrow + k0 + s * 32) : u32x4{0u, 0u, 0u, 0u};
+    for (int k0 = 0; k0 < Kw; k0 += CH * 32) {
+        u32x4 wv[CH], xv[CH][MT];
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
-            if (k0 + s * 32 < Kq) {
+            const bool ok = k0 + s * 32 < Kw;
+            wv[s] = ok ? ld_stream16(wrow + k0 + s * 32) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const u32x4 xv = *reinterpret_cast<const u32x4*>(xrow[t] + k0 + s * 32);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv), acc[t], 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < MT; ++t) xv[s][t] = ok ? *reinterpret_cast<const u32x4*>(xrow[t] + k0 + s * 32) : u32x4{0u, 0u, 0u, 0u};
         }
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv[s][t]), acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&red[w][t][lane][0]) = acc[t];
     __syncthreads();
-    // epilogue: wave t finishes batch tile t (tiles beyond the four waves do not exist: MT <= 4)
+    // epilogue: wave t finishes batch tile t (MT <= 4)
     if (w >= MT) return;
     const int t = w;
     f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][t][lane][0]);
@@ -82,6 +87,12 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
     if (b >= a.B) return;
     const int r0 = n0 + kg * 4;                           // first of this lane's four consecutive output rows
     float o[4] = {v.x, v.y, v.z, v.w};
+    if (a.ksplit > 1) {                                   // raw partial sums; bias / residual / norm happen in the consumer's prologue
+        float* yp = a.y + ((size_t)blockIdx.y * a.B + b) * a.y_stride;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r0 + r < a.N) yp[r0 + r] = o[r];
+        return;
+    }
     const int pos = a.epi == EPI_QKV ? a.st[b].pos : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -106,20 +117,32 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
     }
 }
 
+// K split over blocks for matrices with few row tiles (every CU should stream): up to 4 when N <= 2048 and K allows it
+inline int gemm_dec_ksplit(int N, int K) {
+    if (N > 2048) return 1;
+    if (K % (4 * 4 * 32) == 0) return 4;
+    if (K % (4 * 2 * 32) == 0) return 2;
+    return 1;
+}
+
 inline hipError_t launch_gemm_dec(const GemmDecArgs& a, hipStream_t s) {
-    if (a.K % 128 != 0 || a.B < 1 || a.B > 64) return hipErrorInvalidValue;
-    const dim3 grid((a.N + 15) / 16), block(256);
+    if (a.ksplit < 1 || a.K % (4 * a.ksplit * 32) != 0 || a.B < 1 || a.B > 64) return hipErrorInvalidValue;
+    if (a.ksplit > 1 && (!a.y || a.epi != EPI_PLAIN)) return hipErrorInvalidValue;
+    const dim3 grid((a.N + 15) / 16, a.ksplit), block(256);
     const int mt = (a.B + 15) / 16;
-    if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1>), grid, block, 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2>), grid, block, 0, s, a);
-    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_dec_kernel<4>), grid, block, 0, s, a);
+    if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1, 8>), grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2, 8>), grid, block, 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3, 4>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_dec_kernel<4, 4>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
 // ---- per-row prologue: one block per batch row --------------------------------------------------------------------------
 struct RowsProArgs {
-    const float* x; int x_stride;        // [B][K] fp32 (PRO_PLAIN / PRO_LN)
+    const float* x; int x_stride;        // [B][K] fp32 (PRO_PLAIN / PRO_LN); with nparts > 1: partials [nparts][B][x_stride]
+    int nparts; int B;                   // x = sum of nparts partial buffers (fixed order) + bias + res when nparts >= 1
+    const float* bias;                   // [K] or null, added to the summed input
+    const float* res; int res_stride;    // [B][K] fp32 or null, added to the summed input
     const float* ln_g; const float* ln_b; float ln_eps;
     const float* attn_ws; size_t attn_ws_stride; int attn_heads;      // PRO_ATTN: K = heads * 64
     float* xn_out; int xn_stride;        // prologue(x) fp32 (the residual of a later epilogue) or null
@@ -149,6 +172,30 @@ __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
         for (int j = 0; j < NCH; ++j) {
             const int idx = tid + 256 * j;
             xv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(x + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // split-K producer: add the other partials in order, then the deferred epilogue (bias, residual)
+        for (int p = 1; p < a.nparts; ++p) {
+            const float* xp = x + (size_t)p * a.B * a.x_stride;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(xp + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            }
+        }
+        if (a.res) {
+            const float* rp = a.res + (size_t)b * a.res_stride;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int idx = tid + 256 * j;
+                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            }
         }
     }
     if constexpr (PRO == PRO_LN) {
