@@ -143,9 +143,161 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
+// ---- bf16 policy: the same flash structure on the matrix cores ------------------------------------------------------------
+// One block = 64 query rows of one head, one wave = 16 of them.  Per 64-key tile: K (row-major) and V (transposed) are
+// staged in LDS as bf16 (the policy's rounding point); S = Q K^T with v_mfma_f32_16x16x32_bf16 (A = Q fragment from
+// registers, B = K rows straight out of LDS with ds_read_b128); the softmax runs in registers on the accumulator layout
+// (row = (lane >> 4) * 4 + r, key = lane & 15: the 16 lanes of a DPP row share a query row, so row max / row sum are DPP
+// reductions); P is rounded to bf16, turned into A fragments through a per-wave LDS patch, and O += P V uses the transposed
+// V tile as the B operand.  Scores, softmax statistics and the output accumulate in fp32.
+typedef __bf16 attn_bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int AM_LD = 72;                // bf16 elements per LDS row: 64 + 8 pad (144-byte rows keep ds_read_b128 aligned)
+
+__device__ inline float row_max16(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AM_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * AM_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][16 * AM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int h = blockIdx.y, q0 = blockIdx.x * 64;
+
+    // Q fragments of this wave's 16 rows: lane (row m16, dims s*32 + kg*8 .. +8)
+    attn_bf16x8_t qa[2];
+    {
+        const int qrow = q0 + w * 16 + m16;
+        const bool ok = qrow < a.Sq;
+        const float* qp = a.Q + (size_t)(ok ? qrow : 0) * a.q_rs + (size_t)h * a.q_hs + kg * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+            if (ok) { t0 = *reinterpret_cast<const f32x4*>(qp + s2 * 32); t1 = *reinterpret_cast<const f32x4*>(qp + s2 * 32 + 4); }
+            u32x4 pk;
+            pk.x = (uint32_t)f2bf(t0.x) | ((uint32_t)f2bf(t0.y) << 16); pk.y = (uint32_t)f2bf(t0.z) | ((uint32_t)f2bf(t0.w) << 16);
+            pk.z = (uint32_t)f2bf(t1.x) | ((uint32_t)f2bf(t1.y) << 16); pk.w = (uint32_t)f2bf(t1.z) | ((uint32_t)f2bf(t1.w) << 16);
+            qa[s2] = __builtin_bit_cast(attn_bf16x8_t, pk);
+        }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[4] = {-1e30f, -1e30f, -1e30f, -1e30f}, lsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    int kv_end = a.Sk;
+    if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + 63, a.Sq - 1) + 1);
+    const int skey = tid >> 2, sd = (tid & 3) * 16;       // staging: 4 threads per key row, 16 dims each
+    const int qrow_base = q0 + w * 16 + kg * 4;           // accumulator rows of this lane: qrow_base + r
+
+    for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+        {
+            const int kp = kv0 + skey;
+            f32x4 kk[4], vv[4];
+            if (kp < a.Sk) {
+                const float* kptr = a.K + (size_t)kp * a.k_rs + (size_t)h * a.k_hs + sd;
+                const float* vptr = a.V + (size_t)kp * a.v_rs + (size_t)h * a.v_hs + sd;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { kk[i] = *reinterpret_cast<const f32x4*>(kptr + 4 * i); vv[i] = *reinterpret_cast<const f32x4*>(vptr + 4 * i); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { kk[i] = f32x4{0, 0, 0, 0}; vv[i] = f32x4{0, 0, 0, 0}; }
+            }
+            __syncthreads();                             // previous tile fully consumed
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                u32x4 pk;
+                pk.x = (uint32_t)f2bf(kk[2 * i].x) | ((uint32_t)f2bf(kk[2 * i].y) << 16); pk.y = (uint32_t)f2bf(kk[2 * i].z) | ((uint32_t)f2bf(kk[2 * i].w) << 16);
+                pk.z = (uint32_t)f2bf(kk[2 * i + 1].x) | ((uint32_t)f2bf(kk[2 * i + 1].y) << 16); pk.w = (uint32_t)f2bf(kk[2 * i + 1].z) | ((uint32_t)f2bf(kk[2 * i + 1].w) << 16);
+                *reinterpret_cast<u32x4*>(&Ks[skey * AM_LD + sd + 8 * i]) = pk;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                Vt[(sd + 4 * i + 0) * AM_LD + skey] = f2bf(vv[i].x);
+                Vt[(sd + 4 * i + 1) * AM_LD + skey] = f2bf(vv[i].y);
+                Vt[(sd + 4 * i + 2) * AM_LD + skey] = f2bf(vv[i].z);
+                Vt[(sd + 4 * i + 3) * AM_LD + skey] = f2bf(vv[i].w);
+            }
+            __syncthreads();
+        }
+        // S = Q K^T for this wave's 16 rows x 64 keys
+        f32x4 sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 kb = *reinterpret_cast<const u32x4*>(&Ks[(j * 16 + m16) * AM_LD + s2 * 32 + kg * 8]);
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[s2], __builtin_bit_cast(attn_bf16x8_t, kb), sc[j], 0, 0, 0);
+            }
+        }
+        // scale + mask, online softmax per accumulator row r
+        float p[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kv0 + j * 16 + m16;
+                const bool valid = key < a.Sk && (a.causal_offset < 0 || key <= a.causal_offset + qrow_base + r);
+                const float v = valid ? sc[j][r] * a.scale : -INFINITY;
+                p[j][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = row_max16(mx);
+            const float mnew = fmaxf(mrun[r], mx);
+            const float alpha = expf(mrun[r] - mnew);
+            mrun[r] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = (p[j][r] == -INFINITY) ? 0.f : expf(p[j][r] - mnew);
+                p[j][r] = e;
+                ps += e;
+            }
+            lsum[r] = lsum[r] * alpha + ps;               // per-lane partial of the row sum (alpha is row-uniform)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t][r] *= alpha;
+        }
+        // P (bf16) -> this wave's LDS patch in row-major [row][key], then back as A fragments
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[w][(kg * 4 + r) * AM_LD + j * 16 + m16] = f2bf(p[j][r]);
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const u32x4 pa = *reinterpret_cast<const u32x4*>(&Ps[w][m16 * AM_LD + s2 * 32 + kg * 8]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(&Vt[(t * 16 + m16) * AM_LD + s2 * 32 + kg * 8]);
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(attn_bf16x8_t, pa), __builtin_bit_cast(attn_bf16x8_t, vb), o[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = qrow_base + r;
+        const float l = row_sum16(lsum[r]);
+        if (qrow < a.Sq) {
+            const float inv = 1.0f / l;
+            float* op = a.O + (size_t)qrow * a.o_rs + h * 64 + m16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) op[t * 16] = o[t][r] * inv;
+        }
+    }
+}
+
+// round_bf16 != 0 (bf16 policy): matrix cores; == 0 (fp32 "exact" policy): the exact-fp32 VALU kernel above
 inline hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.Sq <= 0) return hipSuccess;
-    hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H), dim3(256), 0, s, a);
+    if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.Sq + 63) / 64, a.H), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -132,10 +132,13 @@ class Oracle:
         return F.layer_norm(x, (x.shape[-1],), self.sd[prefix + wkey], self.sd[prefix + bkey], eps)
 
     def attention(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-                  causal_offset: Optional[int] = None, q_chunk: int = 512) -> torch.Tensor:
+                  causal_offset: Optional[int] = None, q_chunk: int = 512, dense: bool = True) -> torch.Tensor:
         """softmax_fp32(q k^T * scale) v per head.  q: (B,Sq,H,64), k/v: (B,Sk,H,64) -> (B,Sq,H*64).
 
-        causal_offset = number of cached positions before q's first row (query i sees keys <= offset+i)."""
+        causal_offset = number of cached positions before q's first row (query i sees keys <= offset+i).
+        bf16 policy, dense=True (encoder / prefill / detokenizer: the engine's matrix-core attention): the probabilities
+        that multiply V are rounded to bf16 while the normaliser sums them in fp32; dense=False (the single-query decode
+        kernel) keeps them fp32."""
         q, k, v = self.rin(q), self.rin(k), self.rin(v)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
@@ -149,8 +152,13 @@ class Oracle:
                 qi = torch.arange(s, e)[:, None] + causal_offset
                 kj = torch.arange(Sk)[None, :]
                 w = w.masked_fill(kj > qi, float("-inf"))
-            w = torch.softmax(w.float(), dim=-1)
-            out[:, s:e] = (w @ vt).permute(0, 2, 1, 3).reshape(B, e - s, H * D)
+            if self.policy == "bf16" and dense:
+                w = w.float()
+                pe = torch.exp(w - w.max(dim=-1, keepdim=True).values)
+                o = (bf16r(pe) @ vt) / pe.sum(dim=-1, keepdim=True)
+            else:
+                o = torch.softmax(w.float(), dim=-1) @ vt
+            out[:, s:e] = o.permute(0, 2, 1, 3).reshape(B, e - s, H * D)
         return out
 
     # ------------------------------------------------------------------ point encoder (miche)
@@ -264,7 +272,8 @@ class Oracle:
                     k = torch.cat([pk, k], dim=1)
                     v = torch.cat([pv, v], dim=1)
                 cache[n] = (k, v)
-            a = self.attention(q, k, v, scale=0.125, causal_offset=past)
+            # S == 1 with a cache = one decode step (fp32 probabilities); everything else is the dense prefill kernel
+            a = self.attention(q, k, v, scale=0.125, causal_offset=past, dense=not (S == 1 and past > 0))
             h = self.ln(h + self.linear(a, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias"),
                         p + "self_attn_layer_norm.", 1e-5)
             f = F.relu(self.linear(h, p + "fc1.weight", p + "fc1.bias"))

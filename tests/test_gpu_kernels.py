@@ -115,8 +115,8 @@ def test_layernorm(lib):
         assert float((y.cpu() - ref).abs().max()) < 2e-5
 
 
-def _attn_ref(q, k, v, scale, causal_offset, rnd):
-    # q (Sq,H,64) k,v (Sk,H,64)
+def _attn_ref(q, k, v, scale, causal_offset, rnd, round_p=False):
+    # q (Sq,H,64) k,v (Sk,H,64); rnd: q,k,v rounded to bf16; round_p: the probabilities that multiply V rounded to bf16
     if rnd:
         q, k, v = _bf(q), _bf(k), _bf(v)
     w = torch.einsum("qhd,khd->hqk", q.double(), k.double()) * scale
@@ -124,11 +124,17 @@ def _attn_ref(q, k, v, scale, causal_offset, rnd):
         Sq, Sk = q.shape[0], k.shape[0]
         mask = torch.arange(Sk)[None, :] > (torch.arange(Sq)[:, None] + causal_offset)
         w = w.masked_fill(mask[None], float("-inf"))
+    if round_p:
+        pe = torch.exp(w - w.max(dim=-1, keepdim=True).values)
+        o = torch.einsum("hqk,khd->qhd", _bf(pe.float()).double(), v.double()) / pe.sum(dim=-1).transpose(0, 1)[..., None]
+        return o.float().reshape(q.shape[0], -1)
     p = torch.softmax(w, dim=-1)
     return torch.einsum("hqk,khd->qhd", p, v.double()).float().reshape(q.shape[0], -1)
 
 
-@pytest.mark.parametrize("rnd", [0, 1], ids=["f32", "bf16in"])
+# rnd 0: fp32 policy (exact VALU kernel); 1: bf16 policy = MFMA kernel (q, k, v and P rounded to bf16, fp32 accumulate);
+# 2: the VALU kernel on bf16-rounded q, k, v with fp32 probabilities
+@pytest.mark.parametrize("rnd", [0, 1, 2], ids=["f32", "bf16mfma", "bf16in"])
 @pytest.mark.parametrize("Sq,Sk,H,layout,causal", [(257, 4096, 12, "cross", -1), (257, 257, 12, "interleaved", -1), (257, 257, 16, "std", 0),
                                                     (1057, 1057, 12, "std", -1), (17, 17, 2, "std", 0), (70, 130, 2, "std", 60)])
 def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
@@ -136,7 +142,7 @@ def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
     q = torch.randn(Sq, H, 64, generator=g)
     k = torch.randn(Sk, H, 64, generator=g)
     v = torch.randn(Sk, H, 64, generator=g)
-    ref = _attn_ref(q, k, v, 0.125, causal, rnd)
+    ref = _attn_ref(q, k, v, 0.125, causal, rnd != 0, round_p=(rnd == 1))
     dev = "cuda"
     if layout == "std":          # q | k | v blocks of H*64 (OPT / BERT fused projection)
         assert Sq == Sk or True
@@ -161,7 +167,10 @@ def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
     torch.cuda.synchronize()
     del args
     assert not torch.isnan(O).any()
-    assert float((O.cpu() - ref).abs().max()) < 2e-5
+    err = float((O.cpu() - ref).abs().max())
+    # MFMA kernel: P is rounded relative to the RUNNING row maximum (online softmax), the reference relative to the final
+    # one, so individual p differ by one bf16 ulp (2^-9 relative); the weighted average over keys stays well below that
+    assert err < (2e-3 if rnd == 1 else 2e-5), err
 
 
 @pytest.mark.parametrize("kvdtype", [0, 1], ids=["f32", "bf16"])
