@@ -111,8 +111,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL path runs even with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from meshanything_amd.engine import Engine
@@ -126,7 +128,7 @@ def main():
         sd.update(synthetic_state_dict(cfg))                # random-init weights in the reference key layout (no network)
         return sd.items()
     # weights travel once, rank 0 -> all, as ONE RCCL broadcast of the packed arena over xGMI
-    dp.load_weights_dp(eng, items, rank, world)
+    dp.load_weights_dp(eng, items, rank, world, force_broadcast=use_dist)
     t_load = time.time() - t_load
 
     # shapes of this rank: global shape index g = rank * batch + j; shape 0 is pc_examples/mouse.npy after Dataset
@@ -146,17 +148,17 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -246,7 +248,7 @@ def main():
             "weights_load_s": round(t_load, 2), "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -88,13 +88,14 @@ def broadcast_host_arena(arena: Optional[np.ndarray], nbytes: int, src: int = 0)
     return t.numpy()
 
 
-def load_weights_dp(engine, items_fn: Callable[[], Iterable[Tuple[str, object]]], rank: int, world: int, src: int = 0) -> None:
+def load_weights_dp(engine, items_fn: Callable[[], Iterable[Tuple[str, object]]], rank: int, world: int, src: int = 0,
+                    force_broadcast: bool = False) -> None:
     """Rank `src` reads the checkpoint (items_fn is only called there) and packs it into its device arena; every other rank
     receives the arena in ONE broadcast on the device (RCCL over xGMI) -- the DDP initial parameter broadcast of the
     reference, main.py:146 -- and marks its weights loaded."""
     if rank == src:
         engine.load_weights(items_fn())
-    if world > 1:
+    if world > 1 or (force_broadcast and dist.is_initialized()):
         arena = engine.arena_tensor()                # uint8 view of the device arena
         dist.broadcast(arena, src=src)
         torch.cuda.synchronize()
