@@ -174,35 +174,80 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
             chosen = bi;
         }
     } else {
+        // top-k by radix selection (4 passes of an 8-bit histogram over order-preserving integer keys) instead of k argmax
+        // sweeps: ~10 us instead of ~190 us for k = 50 over 8195 logits.  Keeps every score >= the k-th largest
+        // (TopKLogitsWarper semantics: ties at the threshold stay), up to PICK_KMAX candidates.
+        __shared__ unsigned hist[16 * 256], wtot[4];      // 16 privatised copies: logits cluster in a few bins (same-address LDS atomics serialise)
+        __shared__ unsigned sel_prefix, sel_krem;
+        __shared__ int ncand;
         const int k = min(min(st->top_k, V), PICK_KMAX);
         for (int i = tid; i < V; i += 256) dyn[i] = (st->suppress_eos && i == TOK_EOS) ? -INFINITY : logits[i];
+        if (tid == 0) { sel_prefix = 0u; sel_krem = (unsigned)k; ncand = 0; }
         __syncthreads();
-        for (int round = 0; round < k; ++round) {
-            float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int i = tid; i < V; i += 256) { const float v = dyn[i]; if (arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
+        auto key_of = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        for (int shift = 24; shift >= 0; shift -= 8) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (arg_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-            }
-            if (lane == 0) { rv[w] = bv; ri[w] = bi; }
+            for (int c = 0; c < 16; ++c) hist[c * 256 + tid] = 0u;
             __syncthreads();
-            if (tid == 0) {
-                for (int i = 1; i < 4; ++i) if (arg_better(rv[i], ri[i], bv, bi)) { bv = rv[i]; bi = ri[i]; }
-                cv[round] = bv; ci[round] = bi;
-                if (bi < V) dyn[bi] = -INFINITY;      // selected: removed from later rounds (also if bv == -inf)
+            const unsigned prefix = sel_prefix;
+            const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < V; i += 256) {
+                const unsigned kk = key_of(dyn[i]);
+                if ((kk & himask) == (prefix & himask)) atomicAdd(&hist[(lane & 15) * 256 + ((kk >> shift) & 0xffu)], 1u);
+            }
+            __syncthreads();
+            {   // suffix[t] = number of keys in bins >= t (parallel: in-wave shuffle scan, then the waves' totals through LDS);
+                // the selected bin is the largest t with suffix[t] >= k_rem
+                unsigned v = 0u;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) v += hist[c * 256 + tid];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_down(v, o, 64); if (lane + o < 64) v += up; }
+                if (lane == 0) wtot[w] = v;
+                __syncthreads();
+                for (int ww = w + 1; ww < 4; ++ww) v += wtot[ww];
+                const unsigned next = __shfl_down(v, 1, 64);                   // suffix[t + 1] inside the wave
+                unsigned above = 0u;                                            // suffix[t + 1]: keys in strictly higher bins
+                if (lane < 63) above = next; else for (int ww = w + 1; ww < 4; ++ww) above += wtot[ww];
+                const unsigned krem = sel_krem;
+                __syncthreads();                                                // everyone has read sel_krem / wtot
+                if (v >= krem && above < krem) { sel_krem = krem - above; sel_prefix = prefix | ((unsigned)tid << shift); }
             }
             __syncthreads();
         }
+        const unsigned thr = sel_prefix;                  // key of the k-th largest score
+        for (int i = tid; i < V; i += 256) {
+            if (key_of(dyn[i]) >= thr) {
+                const int slot = atomicAdd(&ncand, 1);
+                if (slot < PICK_KMAX) { cv[slot] = dyn[i]; ci[slot] = i; }
+            }
+        }
+        __syncthreads();
+        const int nc = min(ncand, PICK_KMAX);
+        // order the candidates: descending score, ties by ascending index (rank by counting, one wave)
+        __shared__ float sv[PICK_KMAX]; __shared__ int si[PICK_KMAX];
+        if (tid < PICK_KMAX) {
+            if (tid < nc) {
+                const float v = cv[tid]; const int ix = ci[tid];
+                int rank = 0;
+                for (int j = 0; j < nc; ++j) if (arg_better(cv[j], ci[j], v, ix)) ++rank;
+                sv[rank] = v; si[rank] = ix;
+            }
+        }
+        __syncthreads();
+        __shared__ float se[PICK_KMAX];
+        if (tid < PICK_KMAX) se[tid] = tid < nc ? expf(sv[tid] - sv[0]) : 0.f;
+        __syncthreads();
         if (tid == 0) {
             // candidates are in descending order.  top-p: drop the ascending prefix whose cumulative mass <= 1 - top_p
+            const int kk = nc;
             float e[PICK_KMAX];
             float sum = 0.f;
-            for (int j = 0; j < k; ++j) { e[j] = expf(cv[j] - cv[0]); sum += e[j]; }
-            const float thr = (float)(1.0 - (double)st->top_p);
-            int keep = k;
+            for (int j = 0; j < kk; ++j) { e[j] = se[j]; sum += e[j]; }
+            const float thr_p = (float)(1.0 - (double)st->top_p);
+            int keep = kk;
             float cum = 0.f;
-            for (int j = k - 1; j >= 1; --j) { cum += e[j] / sum; if (cum <= thr) keep = j; else break; }
+            for (int j = kk - 1; j >= 1; --j) { cum += e[j] / sum; if (cum <= thr_p) keep = j; else break; }
             float sum2 = 0.f;
             for (int j = 0; j < keep; ++j) sum2 += e[j];
             const int t = st->t;
@@ -210,7 +255,7 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
             int pick = keep - 1;
             float acc = 0.f;
             for (int j = 0; j < keep; ++j) { acc += e[j] / sum2; if (acc > u) { pick = j; break; } }
-            chosen = ci[pick];
+            chosen = si[pick];
         }
     }
     __syncthreads();
