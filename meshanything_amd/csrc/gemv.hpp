@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 
 // ---- host-side dispatch ------------------------------------------------------------------------------------------
 struct GemvShape { int ksplit, lpl, rpw; };
-// rows per wave for the big matrices (engine option "gemv_rpw"): 1 = most blocks, 2 = half the blocks / input copies
-inline int& gemv_rpw_big() { static int v = 1; return v; }
+// rows per wave for the big matrices (engine option "gemv_rpw"): 1 = most blocks, 2 = half the blocks / input copies (default:
+// measured 1.4 % faster per decode step, profiles/r01_ab_rows_per_wave.txt)
+inline int& gemv_rpw_big() { static int v = 2; return v; }
 
 template <typename WT>
 inline GemvShape gemv_shape(int N, int K) {
