@@ -11,6 +11,9 @@ cites the reference lines it follows.  Third-party arithmetic that is not under 
 `GenerationMixin.generate` and its logits warpers, BERT layers) is restated from the published
 algorithm; where the container holds a newer copy the restatement cites it.
 
+PIN STATUS: every function the reference's own code can execute here is pinned against that code's output (below);
+the `generate()` loop as a whole is PARITY UNPINNED (the reference cannot run it in this container).
+
 How it is pinned: the reference has no tests and no golden vectors, so the oracle
 is pinned against outputs of the reference's *own code* run in the authoring container
 (`tests/golden/make_golden.py` imports `/root/reference` and writes `tests/golden/*.npz`;
