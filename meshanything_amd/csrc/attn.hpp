@@ -23,6 +23,8 @@ struct AttnArgs {
     float scale;
     int causal_offset;                  // < 0: full attention; else query i sees keys <= causal_offset + i
     int round_bf16;
+    // batch of independent samples: grid.z = sample, element strides between samples (0 / 1 launch at batch 1)
+    size_t q_bs = 0, k_bs = 0, v_bs = 0, o_bs = 0; int batch = 1;
 };
 
 constexpr int ATT_LD = 68;
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int tid = threadIdx.x, r = tid >> 2, c = tid & 3;
     const int h = blockIdx.y;
     const int q0 = blockIdx.x * 64;
+    a.Q += blockIdx.z * a.q_bs; a.K += blockIdx.z * a.k_bs; a.V += blockIdx.z * a.v_bs; a.O += blockIdx.z * a.o_bs;
     const int m = q0 + r;
     const bool row_ok = m < a.Sq;
 
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m16 = lane & 15, kg = lane >> 4;
     const int h = blockIdx.y, q0 = blockIdx.x * 64;
+    a.Q += blockIdx.z * a.q_bs; a.K += blockIdx.z * a.k_bs; a.V += blockIdx.z * a.v_bs; a.O += blockIdx.z * a.o_bs;
 
     // Q fragments of this wave's 16 rows: lane (row m16, dims s*32 + kg*8 .. +8)
     attn_bf16x8_t qa[2];
@@ -296,8 +300,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 // round_bf16 != 0 (bf16 policy): matrix cores; == 0 (fp32 "exact" policy): the exact-fp32 VALU kernel above
 inline hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.Sq <= 0) return hipSuccess;
-    if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.Sq + 63) / 64, a.H), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H), dim3(256), 0, s, a);
+    if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

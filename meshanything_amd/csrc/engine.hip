@@ -90,6 +90,8 @@ struct ma_engine {
     float *w_feat = nullptr, *w_data = nullptr, *w_dataln = nullptr, *w_kv = nullptr, *w_a = nullptr, *w_b = nullptr, *w_c = nullptr,
           *w_qkv = nullptr, *w_mlp = nullptr, *w_lat = nullptr, *w_cat = nullptr, *w_mean = nullptr;
     float *w_x = nullptr, *w_fein = nullptr, *w_fe = nullptr, *w_logit = nullptr;
+    float *p_h = nullptr, *p_qkv = nullptr, *p_att = nullptr, *p_y = nullptr, *p_ffn = nullptr;    // prefill workspace: prefill_rows samples stacked
+    int prefill_rows = 1;
     unsigned char* w_mask = nullptr;
     float *w_latents = nullptr, *w_prefix = nullptr, *w_coords = nullptr;   // ma_forward intermediates (max_batch rows)
     long long *w_tokens = nullptr, *w_ids = nullptr;
@@ -140,8 +142,10 @@ void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::str
     HIP_CHECK(hipGetLastError());
 }
 void attention(ma_engine* e, hipStream_t s, const float* Q, int q_rs, int q_hs, const float* K, int k_rs, int k_hs, const float* Vp, int v_rs,
-               int v_hs, float* O, int o_rs, int Sq, int Sk, int H, int causal_offset) {
+               int v_hs, float* O, int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0,
+               size_t o_bs = 0) {
     AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 1 : 0};
+    a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     HIP_CHECK(launch_attention(a, s));
 }
 void copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int rows, int cols) {
@@ -149,8 +153,8 @@ void copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int r
     HIP_CHECK(hipGetLastError());
 }
 void add_rows(hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
-              float* out, int ld_out, int rows, int cols) {
-    hipLaunchKernelGGL(add_rows_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out, ld_out, rows, cols);
+              float* out, int ld_out, int rows, int cols, int tab_mod = 0) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out, ld_out, rows, cols, tab_mod);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -478,50 +482,55 @@ void launch_step(ma_engine* e, hipStream_t s, int B) {
     else { StepTimer none; enqueue_decode_step(e, s, -1, none, Rows{0, B}); }
 }
 
-// prefill of ONE row: ShapeOPTDecoder.forward inputs_embeds branch (shape_opt.py:331-364) + 24 post-LN layers, causal, on the
-// T prefix rows; fills the row's KV planes and leaves the row's first logits in d_logits[row]
-void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row) {
+// prefill of rows row0 .. row0+B-1 in ONE pass (the samples are stacked along the GEMM rows: M = B * T): ShapeOPTDecoder.forward
+// inputs_embeds branch (shape_opt.py:331-364) + 24 post-LN layers, causal per sample, on the T prefix rows of every sample;
+// fills the rows' KV planes and leaves each row's first logits in d_logits[row]
+void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) {
     const ma_config& c = e->cfg;
-    const int T = e->T, H = c.hidden;
+    const int T = e->T, H = c.hidden, M = B * T;
     StepTimer none;
-    const Rows rw{row, 1};
-    float* h = e->w_x;                       // (T, H)
-    add_rows(s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, T, H);
+    float* h = e->p_h;                       // (B*T, H)
+    add_rows(s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, M, H, T);
     if (e->opt_prefill_stepwise) {
-        // debug path: feed the prefix rows through the decode-step kernels one position at a time
-        for (int j = 0; j < T; ++j) {
-            hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st + row, 0, j, 0, 1);
-            HIP_CHECK(hipGetLastError());
-            for (int l = 0; l < c.layers; ++l) {
-                if (l == 0) enqueue_layer(e, s, 0, h + (size_t)j * H, nullptr, nullptr, -1, none, rw);
-                else enqueue_layer(e, s, l, e->d_ypre2 + (size_t)row * H, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, -1, none, rw);
+        // debug path: feed the prefix rows through the decode-step kernels one position at a time, one sample at a time
+        for (int b = 0; b < B; ++b) {
+            const Rows rw{row0 + b, 1};
+            for (int j = 0; j < T; ++j) {
+                hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st + row0 + b, 0, j, 0, 1);
+                HIP_CHECK(hipGetLastError());
+                for (int l = 0; l < c.layers; ++l) {
+                    if (l == 0) enqueue_layer(e, s, 0, h + ((size_t)b * T + j) * H, nullptr, nullptr, -1, none, rw);
+                    else enqueue_layer(e, s, l, e->d_ypre2 + (size_t)(row0 + b) * H, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, -1, none, rw);
+                }
             }
+            enqueue_lm_head(e, s, e->d_ypre2 + (size_t)(row0 + b) * H, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, none, rw);
         }
-        enqueue_lm_head(e, s, e->d_ypre2 + (size_t)row * H, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, none, rw);
         return;
     }
-    float* qkv = e->w_qkv;                   // (T, 3H)
-    float* att = e->w_b;                     // (T, H)
-    float* y = e->w_c;                       // (T, H)
-    float* ffn = e->w_mlp;                   // (T, ffn)
+    float* qkv = e->p_qkv;                   // (B*T, 3H)
+    float* att = e->p_att;                   // (B*T, H)
+    float* y = e->p_y;                       // (B*T, H)
+    float* ffn = e->p_ffn;                   // (B*T, ffn)
+    const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = DEC + "layers." + std::to_string(l) + ".";
-        gemm(e, s, h, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * H, T, ACT_NONE);
+        gemm(e, s, h, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * H, M, ACT_NONE);
         const int n = T * c.heads * 64;
-        if (e->bf16) hipLaunchKernelGGL((kv_fill_kernel<bf16_t>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                        reinterpret_cast<bf16_t*>(e->kplane(row, l)), reinterpret_cast<bf16_t*>(e->vplane(row, l)));
-        else hipLaunchKernelGGL((kv_fill_kernel<float>), dim3(ceil_div(n, 256)), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                reinterpret_cast<float*>(e->kplane(row, l)), reinterpret_cast<float*>(e->vplane(row, l)));
+        if (e->bf16) hipLaunchKernelGGL((kv_fill_kernel<bf16_t>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+                                        reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);
+        else hipLaunchKernelGGL((kv_fill_kernel<float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+                                reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
         HIP_CHECK(hipGetLastError());
-        attention(e, s, qkv, 3 * H, 64, qkv + H, 3 * H, 64, qkv + 2 * H, 3 * H, 64, att, H, T, T, c.heads, 0);
-        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, y, H, T, ACT_NONE);
-        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, T, H);
-        gemm(e, s, h, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, ffn, c.ffn, T, ACT_RELU);
-        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, y, H, T, ACT_NONE);
-        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, T, H);
+        attention(e, s, qkv, 3 * H, 64, qkv + H, 3 * H, 64, qkv + 2 * H, 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
+                  (size_t)T * 3 * H, (size_t)T * H);
+        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, y, H, M, ACT_NONE);
+        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, M, H);
+        gemm(e, s, h, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, ffn, c.ffn, M, ACT_RELU);
+        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, y, H, M, ACT_NONE);
+        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, M, H);
     }
-    // only the last prefix row feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
-    enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, 0, nullptr, nullptr, none, rw);
+    // only the last prefix row of every sample feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
+    enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, T * H, nullptr, nullptr, none, Rows{row0, B});
 }
 
 // state records of rows 0..B-1: identical except for the row id and the row's slice of the injected uniforms
@@ -562,7 +571,11 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
     HIP_CHECK(hipGetLastError());
     ensure_graph(e, B);
     init_state(e, s, sc, B, maxn);
-    for (int b = 0; b < B; ++b) prefill(e, s, prefix + (size_t)b * e->T * e->cfg.hidden, b);
+    // prefill in groups of rows (bounded workspace: prefill_rows samples at a time)
+    for (int b0 = 0; b0 < B; b0 += e->prefill_rows) {
+        const int nb = std::min(e->prefill_rows, B - b0);
+        prefill(e, s, prefix + (size_t)b0 * e->T * e->cfg.hidden, b0, nb);
+    }
     if (e->opt_prefill_stepwise) init_state(e, s, sc, B, maxn);         // the stepwise prefill used the state's pos field
     StepTimer none;
     enqueue_pick(e, s, none, Rows{0, B});                                // token 0 (expected bos; dropped later, meshanything.py:166)
@@ -690,6 +703,12 @@ void build_engine(ma_engine* e) {
     e->w_lat = e->dmalloc<float>((size_t)T * W); e->w_cat = e->dmalloc<float>((size_t)T * 2 * W); e->w_mean = e->dmalloc<float>((size_t)T * c.embed_dim);
     e->w_fein = e->dmalloc<float>((size_t)e->nf * 3 * c.codebook_dim); e->w_fe = e->dmalloc<float>((size_t)e->nf * Wt);
     e->w_logit = e->dmalloc<float>((size_t)e->nf * 9 * c.discrete_num); e->w_mask = e->dmalloc<unsigned char>(e->nf);
+    e->prefill_rows = std::min(c.max_batch, 16);                     // 16 x 257 rows per pass: 4112-row GEMMs, ~170 MB of workspace
+    {
+        const size_t PR = (size_t)e->prefill_rows * T;
+        e->p_h = e->dmalloc<float>(PR * H); e->p_qkv = e->dmalloc<float>(PR * 3 * H); e->p_att = e->dmalloc<float>(PR * H);
+        e->p_y = e->dmalloc<float>(PR * H); e->p_ffn = e->dmalloc<float>(PR * c.ffn);
+    }
     const size_t B = c.max_batch;
     e->w_latents = e->dmalloc<float>(B * T * W); e->w_prefix = e->dmalloc<float>(B * T * H);
     e->w_tokens = e->dmalloc<long long>(B * e->maxnew); e->w_ids = e->dmalloc<long long>(B * (size_t)e->nf * 9);

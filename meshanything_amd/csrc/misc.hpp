@@ -46,15 +46,16 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 // out[i][n] = (mask == null || mask[i] ? in[i][n] : 0) + (t0 ? t0[n] : 0) + (tab ? tab[(i + row0) * ld_tab + n] : 0)
 //  - decoder prefill: prefix + cond_embed[0] + embed_positions[2 + i]         (shape_opt.py:331-337, 359-364)
 //  - detokenizer:     point feature + point_pe[i]; masked face embeds + pos_embedding[i]   (meshanything.py:47, 58-60)
+// tab_mod > 0: the table restarts every tab_mod rows (a batch of samples stacked along the rows)
 __global__ void add_rows_kernel(const float* __restrict__ in, int ld_in, const unsigned char* __restrict__ mask,
                                 const float* __restrict__ t0, const float* __restrict__ tab, int ld_tab, int row0,
-                                float* __restrict__ out, int ld_out, int rows, int cols) {
+                                float* __restrict__ out, int ld_out, int rows, int cols, int tab_mod) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * cols) return;
     const int i = idx / cols, n = idx - i * cols;
     float v = (mask == nullptr || mask[i]) ? in[(size_t)i * ld_in + n] : 0.f;
     if (t0) v += t0[n];
-    if (tab) v += tab[(size_t)(i + row0) * ld_tab + n];
+    if (tab) v += tab[(size_t)((tab_mod > 0 ? i % tab_mod : i) + row0) * ld_tab + n];
     out[(size_t)i * ld_out + n] = v;
 }
 
