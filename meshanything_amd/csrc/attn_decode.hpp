@@ -74,18 +74,26 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 }
 
 // ---- producer side ---------------------------------------------------------------------------------------------------
-template <typename KT>
+// ROWWAVE = false: the 4 waves of a block share one (row, head, chunk) and split its positions (batch 1: every CU works on
+// the one sequence).  ROWWAVE = true (batches of >= 4 rows): each wave owns its own batch row's (head, chunk) -- a quarter
+// of the blocks, no block-level merge, and short caches (a chunk of <= 32 positions) keep all four waves busy.
+template <typename KT, bool ROWWAVE>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
                                                           const KT* __restrict__ vc, int max_seq, const DecState* st,
                                                           int len_override, int round_q, float* __restrict__ ws,
-                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride) {
+                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch) {
     constexpr int EPL = 16 / sizeof(KT);     // elements per lane per 16-byte load
     constexpr int LPP = 64 / EPL;            // lanes per position
     constexpr int PPW = 64 / LPP;            // positions per wave-load
     constexpr int U = 32 / PPW;              // loads per lane per operand and round: 32 positions per wave
     constexpr int NS = 4 * PPW;              // softmax states per block
-    const int c = blockIdx.x, h = blockIdx.y, H = gridDim.y, brow = blockIdx.z;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x, h = blockIdx.y, H = gridDim.y;
+    const int brow_raw = ROWWAVE ? blockIdx.z * 4 + w : blockIdx.z;
+    const bool row_ok = brow_raw < batch;
+    const int brow = row_ok ? brow_raw : batch - 1;       // surplus waves shadow the last row and store nothing
+    constexpr int RSH = ROWWAVE ? 5 : 7;                  // positions per round: 32 per wave | 128 per block
+    const int woff = ROWWAVE ? 0 : w * 32;
     const int slot = lane / LPP, dsub = lane % LPP;
     if (trace && threadIdx.x == 0) trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     // batch row (grid.z): its query, its cache planes, its partials, its state
@@ -108,13 +116,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const int per = (len + ATTN_NCHUNK - 1) / ATTN_NCHUNK;
     const int start = c * per;
     const int end = min(len, start + per);
-    const int nround = (max(end - start, 0) + 127) >> 7;
+    const int nround = (max(end - start, 0) + (1 << RSH) - 1) >> RSH;
 
     const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
     const KT* vh = vc + (size_t)h * max_seq * 64 + dsub * EPL;
     u32x4 kA[U], vA[U], kB[U], vB[U];
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
-        const int base = start + (r << 7) + w * 32 + slot;
+        const int base = start + (r << RSH) + woff + slot;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = base + u * PPW;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.f;
     auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
-        const int base = start + (r << 7) + w * 32 + slot;
+        const int base = start + (r << RSH) + woff + slot;
         float d[U];
         float mr = m;
 #pragma unroll
@@ -205,6 +213,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             L = fmaf(sl[w * NQ + i], f, L);
             O = fmaf(so[w * NQ + i][lane], f, O);
         }
+        if constexpr (ROWWAVE) {                            // this wave's partial is final: one (row, head, chunk) per wave
+            if (row_ok) {
+                float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
+                float* op = ws + (size_t)H * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
+                if (lane == 0) { ml[0] = M; ml[1] = L; }
+                op[lane] = O;
+            }
+            return;
+        }
         if (lane == 0) { qm[w] = M; ql[w] = L; }
         qo[w][lane] = O;
     }
@@ -229,9 +246,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 template <typename KT>
 inline hipError_t launch_attn_decode(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
                                      int round_q, float* workspace, hipStream_t s, unsigned long long* trace = nullptr, int batch = 1,
-                                     int q_stride = 0, size_t kv_row_stride = 0) {
-    hipLaunchKernelGGL((attn_decode_kernel<KT>), dim3(ATTN_NCHUNK, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc), reinterpret_cast<const KT*>(vc),
-                       max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride);
+                                     int q_stride = 0, size_t kv_row_stride = 0, bool rowwave = false) {
+    // rowwave: only with the batched MFMA decode path (the row-parallel GEMV path keeps every row's arithmetic identical
+    // to a batch-1 run, including the attention's merge order)
+    if (rowwave && batch >= 4)
+        hipLaunchKernelGGL((attn_decode_kernel<KT, true>), dim3(ATTN_NCHUNK, H, (batch + 3) / 4), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<KT, false>), dim3(ATTN_NCHUNK, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
     return hipGetLastError();
 }
 

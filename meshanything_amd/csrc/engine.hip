@@ -319,7 +319,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             gemm_dec(e, s, a, tm);
         }
         if (tm.on(1)) {
-            hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems);
+            hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems, true);
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
         }
         rows_prologue(e, s, PRO_ATTN, rw, ProIn{}, nullptr, nullptr, nullptr, tm);
