@@ -795,7 +795,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "gemv_rpw") {
-            if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1 or 2");
+            if (value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1, 2 or 4");
             gemv_rpw_big() = (int)value;
             e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, e->cfg.hidden) : gemv_num_blocks<float>(e->V, e->cfg.hidden);
             drop_graphs(e);                              // the captured steps embed grids and arguments: the next generate() re-captures

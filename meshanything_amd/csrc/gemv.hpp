@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     constexpr int KC = LPL > 0 ? KSPLIT * LPL * 64 * VEC : 4;
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ float red[8];
-    __shared__ float lv[8];
+    __shared__ float lv[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int grp = w / KSPLIT, wk = w % KSPLIT;
     const int row0 = blockIdx.x * RPB + grp * RPW;       // first row of this wave's group
@@ -329,21 +329,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 
 // ---- host-side dispatch ------------------------------------------------------------------------------------------
 struct GemvShape { int ksplit, lpl, rpw; };
-// rows per wave for the big matrices (engine option "gemv_rpw"): 1 = most blocks, 2 = half the blocks / input copies (default:
-// measured 1.4 % faster per decode step, profiles/r01_ab_rows_per_wave.txt)
-inline int& gemv_rpw_big() { static int v = 2; return v; }
+// rows per wave for the big matrices (engine option "gemv_rpw"): 1 = most blocks ... 4 = a quarter of the blocks / input copies
+// (default 4: measured 1.4 % (2 vs 1) + 0.5 % (4 vs 2) faster per decode step, profiles/r01_ab_rows_per_wave.txt)
+inline int& gemv_rpw_big() { static int v = 4; return v; }
 
 template <typename WT>
 inline GemvShape gemv_shape(int N, int K) {
     constexpr int VEC = WTraits<WT>::VEC;
     if (K % (64 * VEC) != 0) return {1, 0, 1};
     const int nc = K / (64 * VEC);                       // 16-byte pieces per lane for one row
-    const int rpw = (N >= 2048 && gemv_rpw_big() == 2) ? 2 : 1;
+    const int rpw = N >= 2048 ? gemv_rpw_big() : 1;
     switch (nc) {
-        case 1: return {1, 1, rpw};
+        case 1: return {1, 1, rpw > 2 ? 2 : rpw};
         // > 1024 blocks do not fit the chip at once (8195 lm_head rows: 2049 blocks start over 2.9 us): two rows per wave
-        case 2: return N <= 2048 ? GemvShape{2, 1, 1} : GemvShape{1, 2, N > 4096 ? 2 : rpw};
-        case 4: return {2, 2, N > 4096 ? 2 : rpw};
+        case 2: return N <= 2048 ? GemvShape{2, 1, 1} : GemvShape{1, 2, N > 4096 ? (rpw > 2 ? rpw : 2) : rpw};
+        case 4: return {2, 2, N > 4096 ? 2 : (rpw > 2 ? 2 : rpw)};
         case 8: return {4, 2, 1};
         case 16: return {4, 4, 1};
         default: return {1, 0, 1};
@@ -373,7 +373,7 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s, int batch = 1) {
     const int rpb = (4 / g.ksplit) * g.rpw;
     const dim3 grid((a.N + rpb - 1) / rpb, batch);
 #define MA_GEMV_CASE(KS, LP, RW) if (g.ksplit == KS && g.lpl == LP && g.rpw == RW) { launch_gemv_pro<WT, KS, LP, RW>(a, pro, grid, s); return hipGetLastError(); }
-    MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
+    MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(1, 2, 4) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
     MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)
 #undef MA_GEMV_CASE
     return hipErrorInvalidValue;
