@@ -105,3 +105,24 @@ def test_batch_limit_is_enforced(env):
     from meshanything_amd._lib import MAError
     with pytest.raises(MAError):
         env.model(_clouds(env.cfg, [1, 2, 3]).cuda())                                # max_batch = 2
+
+
+def test_cli_writes_obj_files(tmp_path):
+    """`python main.py --input_path mouse.npy --input_type pc_normal ...` end to end (350M shape, seeded synthetic checkpoint,
+    8-face cap so that it takes seconds): one OBJ per input, faces index existing vertices."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(repo, "tests", "golden", "dataset.npz"))
+    src = tmp_path / "mouse.npy"
+    np.save(src, g["mouse_raw"])
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(repo, "main.py"), "--input_path", str(src), "--input_type", "pc_normal", "--out_dir", str(out),
+                        "--synthetic_weights", "--n_max_triangles", "8", "--seed", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    objs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_gen.obj")]
+    assert len(objs) == 1 and os.path.basename(objs[0]) == "mouse_gen.obj"
+    lines = open(objs[0]).read().splitlines()
+    nv = sum(l.startswith("v ") for l in lines)
+    faces = [[int(t) for t in l.split()[1:]] for l in lines if l.startswith("f ")]
+    assert all(1 <= i <= nv for f in faces for i in f)
+    assert "Generation Start!!!" in r.stdout and "Over!!" in r.stdout
