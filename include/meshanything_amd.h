@@ -75,7 +75,7 @@ typedef struct ma_config {
     int32_t max_batch;     /* largest B accepted by encode/generate/detokenize/forward */
     int32_t dtype;         /* MA_DTYPE_BF16: bf16 weights + KV, GEMM/attention inputs rounded to bf16, fp32 accumulate;
                               MA_DTYPE_F32: everything fp32 ("exact" mode for the parity gates) */
-    int32_t kv_splits;     /* reserved (the decode attention splits the cache in fixed 128-position chunks) */
+    int32_t kv_splits;     /* reserved (the decode attention always splits a head's cache into 16 equal chunks) */
     int32_t use_graph;     /* 1: replay one captured decode step (hipGraph); 0: eager launches */
 } ma_config;
 

@@ -52,7 +52,7 @@ class MAConfig:
     # ---- engine policy ----
     max_batch: int = 1
     dtype: int = DTYPE_BF16
-    kv_splits: int = 0          # reserved (the decode attention splits the cache in fixed 128-position chunks)
+    kv_splits: int = 0          # reserved (the decode attention always splits a head's cache into 16 equal chunks)
     use_graph: int = 1          # capture one decode step in a hipGraph and replay it
 
     # ---- derived ----

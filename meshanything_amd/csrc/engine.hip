@@ -3,8 +3,9 @@
 // Phases (reference: MeshAnything.forward, MeshAnything/models/meshanything.py:134-176):
 //   encode      point cloud -> 257x768 latents -> 257x1024 prefix        (MFMA GEMMs + LDS-tiled attention)
 //   prefill     24 OPT layers over the prefix, fills the KV cache        (same kernels, causal)
-//   decode      <= 7201 steps, each = 147 launches replayed from ONE hipGraph (weight-streaming GEMVs + split-KV attention);
-//               all step-varying scalars live in a device DecState, so the graph never changes
+//   decode      <= 7201 steps, each = 123 launches (batch 1: embed + 24 x [qkv | attention | out_proj+merge | fc1 | fc2] + lm_head
+//               + pick) replayed from ONE hipGraph per batch size; all step-varying scalars live in per-row device DecState
+//               records, so the graph never changes.  Batches of >= 4 rows (bf16) run the same chain as skinny MFMA GEMMs.
 //   detokenize  codebook gather + 6 BERT layers over 1057 tokens + per-coordinate argmax
 #include <hip/hip_runtime.h>
 
