@@ -213,10 +213,10 @@ def main():
         if args.batch > 1 and args.dtype == "bf16" and args.batch >= 4:
             roofline["kernel"] = "gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream: 98 skinny GEMMs + 73 prologues per step)"
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))
         batched = None
-        if args.batch == 1 and not args.no_batched_table and args.dtype == "bf16":
+        if args.batch == 1 and not args.no_batched_table and args.dtype == "bf16" and world == 1:
             # configs 3-5 in brief: the decode step when 8 / 64 shapes share the weight stream (mid context, graph replay)
             eng.close()
             torch.cuda.empty_cache()
