@@ -7,7 +7,8 @@
 Same flags as the reference.  Differences, all forced by the environment (no network, no trimesh): the checkpoint is
 read from `--pretrained_weights` (the reference ignores that flag and downloads `MeshAnything_350m.pth`, main.py:95-98;
 `--synthetic_weights` uses the seeded random checkpoint of the tests instead), `--input_type mesh` is not available
-(needs trimesh / mesh2sdf surface sampling) and the exported OBJ is not normal-fixed (`meshanything_amd/mesh_export.py`).
+(needs trimesh / mesh2sdf surface sampling); the mesh clean-up of main.py:156-175 is restated without trimesh in
+`meshanything_amd/mesh_export.py`.
 Multi-GPU: one process per GPU; rank r takes the shapes i % world == r and the weights travel in one RCCL broadcast.
 """
 import argparse
@@ -43,7 +44,7 @@ def main():
     from meshanything_amd import dp
     from meshanything_amd.checkpoint import load_safetensors_items, synthetic_items
     from meshanything_amd.data import Dataset
-    from meshanything_amd.mesh_export import faces_from_coords, write_obj
+    from meshanything_amd.mesh_export import faces_from_coords, fix_normals, write_obj
     from meshanything_amd.model import MeshAnything
 
     args = get_args()
@@ -79,6 +80,7 @@ def main():
         outputs = model(pc, sampling=args.sampling).cpu().numpy()
         for d, coords in zip(data, outputs):
             verts, faces = faces_from_coords(coords)
+            faces = fix_normals(verts, faces)
             path = os.path.join(out_dir, f'{d["uid"]}_gen.obj')
             write_obj(path, verts, faces)
             print(f"{path} Over!!")

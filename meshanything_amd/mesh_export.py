@@ -6,8 +6,11 @@ change the *content* of the file are restated here on exact coordinates (the det
 "same vertex" is exact equality -- no tolerance needed):
   drop NaN faces -> merge identical vertices -> drop faces that repeat an earlier face's vertex SET (trimesh's
   unique_faces sorts each face's indices) -> write OBJ.
-`fix_normals()` (consistent winding + outward orientation, a graph traversal plus a signed-volume test) is NOT restated:
-winding is left as generated.
+`fix_normals()` = trimesh.repair.fix_winding + fix_inversion: faces that share an edge are given consistent winding by a
+breadth-first traversal of the face-adjacency graph (edges shared by exactly two faces), then the whole mesh is flipped
+if its signed volume is negative (multibody=False, trimesh's default).  `fix_normals` below restates that; where a mesh
+is not orientable (or an edge has more than two faces) the result depends on the traversal order, here lowest face index
+first -- trimesh's order comes from networkx and is not reproduced bit for bit.
 """
 from __future__ import annotations
 
@@ -29,6 +32,51 @@ def faces_from_coords(coords: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     _, first = np.unique(key, axis=0, return_index=True)                     # unique_faces: first occurrence of each vertex set
     faces = faces[np.sort(first)]
     return verts.astype(np.float32), faces
+
+
+def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """Consistent winding across shared edges, then outward orientation (positive signed volume).  Returns new faces."""
+    faces = np.array(faces, dtype=np.int64, copy=True)
+    n = len(faces)
+    if n == 0:
+        return faces
+    # undirected edge -> faces using it
+    edge_faces = {}
+    for f in range(n):
+        a, b, c = faces[f]
+        for u, v in ((a, b), (b, c), (c, a)):
+            edge_faces.setdefault((min(u, v), max(u, v)), []).append(f)
+    adj = [[] for _ in range(n)]
+    for (u, v), fs in edge_faces.items():
+        if len(fs) == 2:                                     # manifold edges only, as trimesh.face_adjacency
+            adj[fs[0]].append((fs[1], u, v))
+            adj[fs[1]].append((fs[0], u, v))
+
+    def directed(f, u, v):                                   # does face f traverse the edge as u -> v ?
+        a, b, c = faces[f]
+        return (a == u and b == v) or (b == u and c == v) or (c == u and a == v)
+
+    seen = np.zeros(n, dtype=bool)
+    for root in range(n):
+        if seen[root]:
+            continue
+        seen[root] = True
+        queue = [root]
+        while queue:
+            f = queue.pop(0)
+            for g, u, v in sorted(adj[f]):
+                if seen[g]:
+                    continue
+                # consistently wound neighbours traverse their shared edge in opposite directions
+                if directed(f, u, v) == directed(g, u, v):
+                    faces[g] = faces[g][::-1]
+                seen[g] = True
+                queue.append(g)
+    tri = verts[faces].astype(np.float64)
+    volume = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])).sum() / 6.0
+    if volume < 0:
+        faces = faces[:, ::-1].copy()
+    return faces
 
 
 def write_obj(path: str, verts: np.ndarray, faces: np.ndarray) -> None:

@@ -1,6 +1,6 @@
 import numpy as np
 
-from meshanything_amd.mesh_export import faces_from_coords, write_obj
+from meshanything_amd.mesh_export import faces_from_coords, fix_normals, write_obj
 
 
 def test_faces_from_coords_merges_and_dedups(tmp_path):
@@ -20,3 +20,32 @@ def test_faces_from_coords_merges_and_dedups(tmp_path):
     assert sum(l.startswith("v ") for l in lines) == 4 and sum(l.startswith("f ") for l in lines) == 3
     v0, f0 = faces_from_coords(np.full((4, 3, 3), np.nan, np.float32))
     assert v0.shape == (0, 3) and f0.shape == (0, 3)
+
+
+def _signed_volume(v, f):
+    t = v[f].astype(np.float64)
+    return np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0
+
+
+def test_fix_normals_makes_a_scrambled_tetrahedron_consistent_and_outward():
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    good = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])          # outward: volume +1/6
+    assert abs(_signed_volume(v, good) - 1 / 6) < 1e-9
+    scrambled = good.copy()
+    scrambled[1] = scrambled[1][::-1]
+    scrambled[3] = scrambled[3][::-1]
+    fixed = fix_normals(v, scrambled)
+    assert abs(_signed_volume(v, fixed) - 1 / 6) < 1e-9
+    # every shared edge is traversed in opposite directions by its two faces
+    dirs = {}
+    for a, b, c in fixed:
+        for e in ((a, b), (b, c), (c, a)):
+            dirs[e] = dirs.get(e, 0) + 1
+    assert all((b, a) in dirs for (a, b) in dirs) and all(n == 1 for n in dirs.values())
+    inward = good[:, ::-1]
+    assert abs(_signed_volume(v, fix_normals(v, inward)) - 1 / 6) < 1e-9    # all faces inverted: flipped as a whole
+    assert fix_normals(v, np.zeros((0, 3), np.int64)).shape == (0, 3)
+    two = np.array([[0, 1, 2], [0, 1, 3]])                                   # open surface: made consistent, orientation by volume sign
+    f2 = fix_normals(v, two)
+    e01 = [(f[i], f[(i + 1) % 3]) for f in f2 for i in range(3) if {f[i], f[(i + 1) % 3]} == {0, 1}]
+    assert len(e01) == 2 and e01[0] == e01[1][::-1]
