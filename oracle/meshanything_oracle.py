@@ -11,8 +11,10 @@ cites the reference lines it follows.  Third-party arithmetic that is not under 
 `GenerationMixin.generate` and its logits warpers, BERT layers) is restated from the published
 algorithm; where the container holds a newer copy the restatement cites it.
 
-PIN STATUS: every function the reference's own code can execute here is pinned against that code's output (below);
-the `generate()` loop as a whole is PARITY UNPINNED (the reference cannot run it in this container).
+PIN STATUS: every function the reference's own code can execute here is pinned against that code's output (below); the
+`generate()` loop semantics are pinned against the container's HuggingFace `GenerationMixin.generate` driving this
+oracle's step function (tests/test_generate_loop_vs_hf.py); the reference's ShapeOPT.forward + generate() executed end
+to end by the reference itself is PARITY UNPINNED (it cannot run in this container).
 
 How it is pinned: the reference has no tests and no golden vectors, so the oracle
 is pinned against outputs of the reference's *own code* run in the authoring container
