@@ -13,8 +13,9 @@ algorithm; where the container holds a newer copy the restatement cites it.
 
 PIN STATUS: every function the reference's own code can execute here is pinned against that code's output (below); the
 `generate()` loop semantics are pinned against the container's HuggingFace `GenerationMixin.generate` driving this
-oracle's step function (tests/test_generate_loop_vs_hf.py); the reference's ShapeOPT.forward + generate() executed end
-to end by the reference itself is PARITY UNPINNED (it cannot run in this container).
+oracle's step function (tests/test_generate_loop_vs_hf.py); the reference's own ShapeOPTDecoder.forward is pinned through
+tests/golden/shapeopt_forward.npz (prefix call + cached steps).  PARITY UNPINNED: only the outermost composition, the
+ShapeOPT CausalLM wrapper under transformers==4.39.3 generate() with flash-attn (cannot be constructed in this container).
 
 How it is pinned: the reference has no tests and no golden vectors, so the oracle
 is pinned against outputs of the reference's *own code* run in the authoring container

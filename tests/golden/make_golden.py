@@ -215,6 +215,106 @@ def golden_opt_layers(out, cfg: MAConfig, sd):
     print("opt layers: out absmax", float(x.abs().max()))
 
 
+class _TupleCacheShim:
+    """Duck-typed stand-in for transformers' Cache inside ONE layer call: holds the 4.39.3-style (k, v) tuple of that layer."""
+    def __init__(self, past):
+        self.past, self.present = past, None
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        if self.past is not None:
+            key_states = torch.cat([self.past[0], key_states], dim=2)
+            value_states = torch.cat([self.past[1], value_states], dim=2)
+        self.present = (key_states, value_states)
+        return key_states, value_states
+
+
+class _Layer439(torch.nn.Module):
+    """Adapter: the container's real OPTDecoderLayer (eager attention) behind the transformers==4.39.3 call signature that
+    ShapeOPTDecoder.forward uses (shape_opt.py:403-415): returns (hidden_states, present_key_value), tuple KV cache of shape
+    (B, heads, L, 64), causal attention (the flash-attn path of 4.39.3 gets attention_mask=None = "causal, no padding")."""
+    def __init__(self, layer):
+        super().__init__()
+        self.layer = layer
+
+    def forward(self, hidden_states, attention_mask=None, layer_head_mask=None, past_key_value=None, output_attentions=False, use_cache=False):
+        assert attention_mask is None and not output_attentions           # no padding anywhere in generate() on this path
+        B, S, _ = hidden_states.shape
+        past = 0 if past_key_value is None else past_key_value[0].shape[2]
+        mask = torch.full((S, past + S), float("-inf")).triu(past + 1)[None, None]
+        shim = _TupleCacheShim(past_key_value)
+        out = self.layer(hidden_states, attention_mask=mask, past_key_values=shim)
+        if isinstance(out, tuple):
+            out = out[0]
+        return (out, shim.present) if use_cache else (out,)
+
+
+def golden_shapeopt_forward(out, cfg: MAConfig, sd):
+    """The reference's OWN ShapeOPTDecoder.forward (shape_opt.py:248-438) driven like generate() drives it: one call with
+    inputs_embeds = the prefix (attention_mask of T ones), then decode steps with input_ids (B,1), the returned tuple cache and
+    an attention mask of T+t ones.  Its layers are the container's real OPTDecoderLayer behind a 4.39.3-signature adapter; the
+    un-tied lm_head (shape_opt.py:24,155) is applied to every returned hidden state."""
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+    from MeshAnything.models.shape_opt import ShapeOPTConfig, ShapeOPTDecoder
+    c = ShapeOPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                       num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                       do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu",
+                       bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    c.quantize_codebook_dim = cfg.codebook_dim
+    c.face_per_token = 9
+    c.cond_length = cfg.cond_length
+    c._attn_implementation = "eager"
+    dec = ShapeOPTDecoder(c).eval()
+    dec._use_flash_attention_2 = True                     # the only branch the reference allows (shape_opt.py:347-357); masks stay 2-D
+    for nm in ("extra_embeds.weight", "input_layer.weight", "input_layer.bias", "embed_positions.weight",
+               "token_embed_positions.weight", "cond_embed.weight"):
+        obj = dec
+        parts = nm.split(".")
+        for p_ in parts[:-1]:
+            obj = getattr(obj, p_)
+        getattr(obj, parts[-1]).data.copy_(torch.from_numpy(sd[DEC + nm]))
+    dec.quantize_codebooks = torch.nn.Parameter(torch.from_numpy(sd[DEC + "quantize_codebooks"]))
+    oc = OPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                   num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                   do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu")
+    oc._attn_implementation = "eager"
+    layers = []
+    for i in range(cfg.layers):
+        L = OPTDecoderLayer(oc, layer_idx=i).eval()
+        sub = {k[len(DEC + f"layers.{i}."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(DEC + f"layers.{i}.")}
+        L.load_state_dict(sub, strict=True)
+        layers.append(_Layer439(L))
+    dec.layers = torch.nn.ModuleList(layers)
+    lm_head = torch.from_numpy(sd["transformer.lm_head.weight"])
+    B, T = 2, cfg.cond_length
+    g = torch.Generator().manual_seed(31)
+    prefix = torch.randn(B, T, cfg.hidden, generator=g) * 0.7
+    # teacher-forced tokens: specials mid-sequence, both rows different, more than one face (slot cycle wraps)
+    steps = 13
+    toks = torch.randint(3, cfg.vocab, (B, steps), generator=g)
+    toks[0, 0] = 0; toks[1, 0] = 0                        # the first generated token is expected to be bos
+    toks[0, 5] = 2; toks[1, 7] = 1
+    hs, logits = [], []
+    with torch.no_grad():
+        o = dec(inputs_embeds=prefix, attention_mask=torch.ones(B, T, dtype=torch.long), use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        hs.append(o.last_hidden_state[:, -1])
+        for t in range(1, steps + 1):                     # step t feeds token t-1; the mask covers the prefix and t generated tokens
+            o = dec(input_ids=toks[:, t - 1:t], past_key_values=pkv, attention_mask=torch.ones(B, T + t, dtype=torch.long),
+                    use_cache=True, return_dict=True)
+            pkv = o.past_key_values
+            hs.append(o.last_hidden_state[:, -1])
+        for h in hs:
+            logits.append(h @ lm_head.T)
+    out["sopt_prefix"] = prefix.numpy()
+    out["sopt_tokens"] = toks.numpy()
+    out["sopt_hidden"] = torch.stack(hs, dim=1).numpy()            # (B, steps + 1, H): after the prefill, then after each step
+    out["sopt_logits_cols"] = torch.stack(logits, dim=1)[:, :, :48].numpy()
+    out["sopt_logits_argmax"] = torch.stack(logits, dim=1).argmax(-1).numpy()
+    out["sopt_cache_len"] = np.array([pkv[0][0].shape[2]])
+    print("ShapeOPTDecoder.forward: hidden absmax", float(torch.stack(hs).abs().max()), "cache length", int(pkv[0][0].shape[2]))
+
+
 def golden_detok(out, cfg: MAConfig, sd, tag: str, lat: torch.Tensor, seed: int):
     from MeshAnything.models.meshanything import NoiseResistantDecoder, MeshAnything as RefMeshAnything, undiscretize
     import transformers
@@ -288,6 +388,13 @@ def main():
     _stub_modules()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-shapeopt" in sys.argv:                     # the other fixtures are committed and unchanged
+        tiny = MAConfig.tiny()
+        g = {}
+        golden_shapeopt_forward(g, tiny, synthetic_state_dict(tiny, include_unused=True))
+        np.savez_compressed(os.path.join(HERE, "shapeopt_forward.npz"), **g)
+        print("shapeopt_forward.npz", os.path.getsize(os.path.join(HERE, "shapeopt_forward.npz")) // 1024, "KiB")
+        return
     g = {}
     golden_dataset(g)
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **g)
@@ -304,6 +411,9 @@ def main():
     golden_detok(g, tiny, sd_t, "tiny", lat_t, seed=21)
     golden_warpers(g)
     np.savez_compressed(os.path.join(HERE, "tiny.npz"), **g)
+    g = {}
+    golden_shapeopt_forward(g, tiny, sd_t)
+    np.savez_compressed(os.path.join(HERE, "shapeopt_forward.npz"), **g)
 
     full = MAConfig.full()
     sd_f = synthetic_state_dict(full, include_unused=True)

@@ -101,6 +101,32 @@ def test_opt_layers_match_transformers_and_cache_is_consistent(tiny):
     np.testing.assert_allclose(torch.cat(outs, 1).numpy(), full.numpy(), atol=2e-5, rtol=0)
 
 
+def test_decoder_forward_matches_the_reference_forward(golden_dir):
+    """The reference's OWN `ShapeOPTDecoder.forward` (shape_opt.py:248-438), driven like generate() drives it (prefix call, then
+    cached single-token calls with the growing attention mask), vs the oracle's embed_prefix / embed_tokens / opt_layers /
+    lm_head: hidden state after the prefill and after each of 13 steps, for two rows with specials mid-sequence."""
+    cfg = MAConfig.tiny()
+    o = Oracle(cfg, synthetic_state_dict(cfg), "fp32")
+    g = _load(golden_dir, "shapeopt_forward.npz")
+    prefix = torch.from_numpy(g["sopt_prefix"])
+    toks = torch.from_numpy(g["sopt_tokens"])
+    B, steps = toks.shape
+    assert int(g["sopt_cache_len"][0]) == cfg.cond_length + steps
+    for b in range(B):
+        cache = [None] * cfg.layers
+        h = o.opt_layers(o.embed_prefix(prefix[b:b + 1]), cache)
+        got = [h[0, -1]]
+        for t in range(1, steps + 1):
+            e = o.embed_tokens(toks[b, t - 1:t], torch.tensor([t]))
+            got.append(o.opt_layers(e[None], cache)[0, -1])
+        got = torch.stack(got)
+        np.testing.assert_allclose(got.numpy(), g["sopt_hidden"][b], atol=3e-5, rtol=0)
+        logits = o.lm_head(got)
+        np.testing.assert_allclose(logits[:, :48].numpy(), g["sopt_logits_cols"][b], atol=1e-4, rtol=0)
+        assert np.array_equal(logits.argmax(-1).numpy(), g["sopt_logits_argmax"][b])
+        assert cache[0][0].shape[1] == cfg.cond_length + steps
+
+
 def test_detokenizer_tiny_matches_reference(tiny):
     cfg, o, g = tiny
     x = torch.from_numpy(g["tiny_input"].astype(np.float32))[None]
