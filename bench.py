@@ -115,6 +115,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # RCCL's banner / debug lines must not share stdout with the JSON line
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from meshanything_amd.engine import Engine
