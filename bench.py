@@ -112,10 +112,15 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL path runs even with one rank
+    real_stdout = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # RCCL's banner / debug lines must not share stdout with the JSON line
+        # RCCL prints its version banner with C stdio on stdout at communicator init; stdout must carry exactly ONE JSON line,
+        # so fd 1 points at stderr for the rest of the run and the JSON line is written to the saved descriptor
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from meshanything_amd.engine import Engine
@@ -249,7 +254,10 @@ def main():
             "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
             "weights_load_s": round(t_load, 2), "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(res), flush=True)
+        if real_stdout is not None:
+            os.write(real_stdout, (json.dumps(res) + "\n").encode())
+        else:
+            print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
