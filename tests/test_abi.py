@@ -84,3 +84,22 @@ def test_bad_config_is_rejected_without_a_gpu(lib):
     h = C.c_void_p()
     assert lib.ma_engine_create(C.byref(h), C.byref(c), 0) == -1 and not h.value
     assert b"struct_size" in lib.ma_last_error(None)
+
+
+def test_product_path_fails_loudly_without_a_gpu(lib):
+    """No CPU fallback anywhere in the product: without a GPU the engine and the reference-named facade refuse to construct."""
+    import types
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from meshanything_amd.engine import Engine
+    from meshanything_amd.model import MeshAnything
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(MAConfig.tiny())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MeshAnything(types.SimpleNamespace(llm="facebook/opt-350m", codebook_size=8192, codebook_dim=1024, n_max_triangles=800), device=0)
+    # the product package never imports the oracle
+    import pathlib
+    import re
+    for f in pathlib.Path(REPO, "meshanything_amd").rglob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), flags=re.M), f
