@@ -164,8 +164,9 @@ MA_API int  ma_generate(ma_engine *e, const float *prefix, int B, const ma_sampl
                         int32_t *lengths, int32_t *n_generated, void *stream);
 
 /* replaces: meshanything.py:163-172 (eos-pad to 9F+2, drop first/last, specials -> -1, others -= 3).
- *   tokens (B, max_new_tokens) + n_generated  ->  ids (B, 9*n_max_faces) int64 in [-1, codebook_size) */
-MA_API int  ma_postprocess_tokens(ma_engine *e, const int64_t *tokens, int B, int n_generated, int64_t *ids, void *stream);
+ *   tokens (B rows of n_generated valid columns, ld_tokens elements apart: what generate() returned, in place)
+ *   ->  ids (B, 9*n_max_faces) int64 in [-1, codebook_size) */
+MA_API int  ma_postprocess_tokens(ma_engine *e, const int64_t *tokens, int ld_tokens, int B, int n_generated, int64_t *ids, void *stream);
 
 /* replaces: MeshAnything.get_codes(indices) (meshanything.py:178-212): ids (B, 9F) in [-1, codebook) -> codes (B, 3F, codebook_dim)
  * fp32, the sum of the three residual-VQ rows of every vertex (pad contributes 0) */

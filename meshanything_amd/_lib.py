@@ -64,7 +64,7 @@ SIGNATURES = {
     "ma_process_point_feature": (_I, [_P, _P, _I, _P, _P]),
     "ma_get_codes": (_I, [_P, _P, _I, _P, _P]),
     "ma_generate": (_I, [_P, _P, _I, C.POINTER(SampleCfg), _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
-    "ma_postprocess_tokens": (_I, [_P, _P, _I, _I, _P, _P]),
+    "ma_postprocess_tokens": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "ma_detokenize": (_I, [_P, _P, _P, _I, _P, _P]),
     "ma_forward": (_I, [_P, _P, _I, _I, C.POINTER(SampleCfg), _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P]),
     "ma_op_gemv": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
@@ -88,6 +88,10 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not found: the MI355X HIP library has not been built "
                           f"(run `python __graft_entry__.py` / meshanything_amd.build.build()).  There is no CPU fallback.")
+    from . import build as _build
+    if _build.recorded_hash() != _build.source_hash():
+        raise ImportError(f"{LIB_PATH} was built from different sources than the ones next to it (csrc/*.hip, csrc/*.hpp or "
+                          f"include/meshanything_amd.h changed since): rebuild with `python __graft_entry__.py`.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

@@ -3,12 +3,12 @@
 // Reference: QKVMultiheadAttention / QKVMultiheadCrossAttention (transformer_blocks.py:56-74, 166-185),
 // [3p] flash_attn prefill (shape_opt.py:403-410) and [3p] BERT self-attention (meshanything.py:62-64).
 //
-// Round-1 kernel: flash-style (online softmax, K/V tiles staged in LDS, nothing S x S ever materialised) on the fp32
-// VALU with exact fp32 probabilities, so that both precision policies have oracle-reproducible rounding points
-// (q, k, v optionally rounded to bf16; P stays fp32).  One block = 64 query rows of one head; thread (r, c) owns query
-// row r and the keys j = 4*jj + c of each 64-key tile, keeps a partial (l, o[64]) for them, and the four threads of a
-// row are merged once at the end -- no P exchange.  LDS rows are padded to 68 floats: the four key rows a wave reads
-// per instruction fall on disjoint banks.  An MFMA version (swapped QK^T, in-register softmax) is the planned upgrade.
+// Two kernels, both flash-style (online softmax, K/V tiles staged in LDS, nothing S x S ever materialised):
+//  * attention_kernel (fp32 "exact" policy): fp32 VALU with exact fp32 probabilities.  One block = 64 query rows of one
+//    head; thread (r, c) owns query row r and the keys j = 4*jj + c of each 64-key tile, keeps a partial (l, o[64]) for
+//    them, and the four threads of a row are merged once at the end -- no P exchange.  LDS rows are padded to 68 floats:
+//    the four key rows a wave reads per instruction fall on disjoint banks.
+//  * attention_mfma_kernel (bf16 policy, further down): the same structure on the matrix cores.
 #pragma once
 #include "common.hpp"
 

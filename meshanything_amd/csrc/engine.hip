@@ -661,6 +661,8 @@ void validate_config(const ma_config& c) {
     if (c.n_max_faces < 1 || c.n_max_faces > c.tok_max_pos) bad("n_max_faces out of range");
     if (c.num_latents + 1 + c.n_max_faces * 9 + 2 > c.max_positions) bad("max_positions too small for cond_length + 9*n_max_faces + 2");
     if (c.max_batch < 1 || c.kv_splits < 0 || c.discrete_num < 1 || c.codebook_size < 1) bad("policy field out of range");
+    // pick_kernel parks the V = codebook_size + 3 logits in dynamic LDS next to ~19 KB of static LDS (64 KB per workgroup without opt-in)
+    if ((size_t)(c.codebook_size + 3) * 4 + 20 * 1024 > 64 * 1024) bad("codebook_size too large for the sampler's LDS stage (max 11261)");
 }
 
 void build_engine(ma_engine* e) {
@@ -988,14 +990,15 @@ int ma_generate(ma_engine* e, const float* prefix, int B, const ma_sample_cfg* s
     });
 }
 
-int ma_postprocess_tokens(ma_engine* e, const int64_t* tokens, int B, int n_generated, int64_t* ids, void* stream) {
+int ma_postprocess_tokens(ma_engine* e, const int64_t* tokens, int ld_tokens, int B, int n_generated, int64_t* ids, void* stream) {
     if (!e || !tokens || !ids) return MA_ERR_INVALID;
     return guarded(e, [&] {
         check_batch(e, B);
-        if (n_generated < 0 || n_generated > e->maxnew) throw MaError(MA_ERR_INVALID, "n_generated out of range");
+        if (n_generated < 0 || n_generated > e->maxnew) throw MaError(MA_ERR_INVALID, "n_generated out of range [0, 9*n_max_faces+2]");
+        if (ld_tokens < n_generated) throw MaError(MA_ERR_INVALID, "ld_tokens smaller than n_generated");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const int total = B * (e->maxnew - 2);
-        hipLaunchKernelGGL(postprocess_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(tokens), e->maxnew,
+        hipLaunchKernelGGL(postprocess_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(tokens), ld_tokens,
                            n_generated, e->maxnew, reinterpret_cast<long long*>(ids), B);
         HIP_CHECK(hipGetLastError());
     });
@@ -1024,7 +1027,7 @@ int ma_forward(ma_engine* e, const void* pc, int pc_dtype, int B, const ma_sampl
     if ((rc = ma_encode(e, pc, pc_dtype, B, lat, e->w_prefix, stream)) != MA_OK) return rc;
     if ((rc = ma_generate(e, e->w_prefix, B, sc, tok, lengths, &ngen, stream)) != MA_OK) return rc;
     if (n_generated) *n_generated = ngen;
-    if ((rc = ma_postprocess_tokens(e, tok, B, ngen, idp, stream)) != MA_OK) return rc;
+    if ((rc = ma_postprocess_tokens(e, tok, e->maxnew, B, ngen, idp, stream)) != MA_OK) return rc;
     if ((rc = ma_detokenize(e, idp, lat, B, coords, stream)) != MA_OK) return rc;
     return guarded(e, [&] { HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream))); });
 }

@@ -184,19 +184,29 @@ class Engine:
     def postprocess_tokens(self, results: torch.Tensor) -> torch.Tensor:
         """meshanything.py:163-172.  results (B, n<=max_new) -> ids (B, 9*n_max_faces)."""
         cfg = self.cfg
+        assert results.dim() == 2, results.shape
         B, n = results.shape
-        full = torch.full((B, cfg.max_new_tokens), 2, dtype=torch.int64, device=self.device)
-        full[:, :n] = results.to(self.device)
+        if n > cfg.max_new_tokens:
+            raise ValueError(f"{n} generated tokens per row, but 9*n_max_faces+2 = {cfg.max_new_tokens} is the most generate() can return")
+        t = results.to(self.device, torch.int64)
+        if n > 0 and t.stride(1) != 1:
+            t = t.contiguous()
+        ld = t.stride(0) if (B > 1 and n > 0) else max(n, 1)        # rows are read in place (a [:, :n] view of generate()'s buffer)
         ids = torch.empty(B, cfg.n_max_faces * 9, dtype=torch.int64, device=self.device)
-        self._check(self.lib.ma_postprocess_tokens(self.h, _ptr(full), B, n, _ptr(ids), _stream_ptr()))
+        self._check(self.lib.ma_postprocess_tokens(self.h, _ptr(t), ld, B, n, _ptr(ids), _stream_ptr()))
         return ids
 
     def detokenize(self, ids: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
         """tokenizer(ids, get_codes(ids), point_feature=latents) (meshanything.py:173-174) -> (B, F, 3, 3)."""
         cfg = self.cfg
-        ids = ids.to(self.device, torch.int64).contiguous()
+        ids = ids.to(self.device, torch.int64)
+        ids = ids.reshape(ids.shape[0], -1).contiguous()            # the reference reshapes too (meshanything.py:51)
         latents = latents.to(self.device, torch.float32).contiguous()
         B = ids.shape[0]
+        if tuple(ids.shape) != (B, cfg.n_max_faces * 9):
+            raise ValueError(f"ids must be (B, 9*n_max_faces = {cfg.n_max_faces * 9}), got {tuple(ids.shape)}")
+        if tuple(latents.shape) != (B, cfg.cond_length, cfg.enc_width):
+            raise ValueError(f"point_feature must be ({B}, {cfg.cond_length}, {cfg.enc_width}), got {tuple(latents.shape)}")
         coords = torch.empty(B, cfg.n_max_faces, 3, 3, dtype=torch.float32, device=self.device)
         self._check(self.lib.ma_detokenize(self.h, _ptr(ids), _ptr(latents), B, _ptr(coords), _stream_ptr()))
         return coords

@@ -7,10 +7,14 @@ change the *content* of the file are restated here on exact coordinates (the det
   drop NaN faces -> merge identical vertices -> drop faces that repeat an earlier face's vertex SET (trimesh's
   unique_faces sorts each face's indices) -> write OBJ.
 `fix_normals()` = trimesh.repair.fix_winding + fix_inversion: faces that share an edge are given consistent winding by a
-breadth-first traversal of the face-adjacency graph (edges shared by exactly two faces), then the whole mesh is flipped
-if its signed volume is negative (multibody=False, trimesh's default).  `fix_normals` below restates that; where a mesh
-is not orientable (or an edge has more than two faces) the result depends on the traversal order, here lowest face index
-first -- trimesh's order comes from networkx and is not reproduced bit for bit.
+breadth-first traversal of the face-adjacency graph (edges shared by exactly two faces); then -- `Trimesh.fix_normals`
+resolves `multibody=None` to `body_count > 1`, and MeshAnything outputs usually have several bodies -- every connected
+body whose own signed volume is negative is flipped (one body: the whole mesh by its total volume, which is the same
+thing).  Faces that share no manifold edge with any other face are not part of any body in trimesh's
+`connected_components(face_adjacency)` and keep their winding.  `fix_normals` below restates that; where a body is not
+orientable (or an edge has more than two faces) the result depends on the traversal order, here lowest face index first --
+trimesh's order comes from networkx and is not reproduced bit for bit.  (trimesh is not installed in this image: the
+restatement follows its published algorithm and cannot be pinned against it here.)
 """
 from __future__ import annotations
 
@@ -35,7 +39,8 @@ def faces_from_coords(coords: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
-    """Consistent winding across shared edges, then outward orientation (positive signed volume).  Returns new faces."""
+    """Consistent winding across shared edges, then outward orientation (positive signed volume) per connected body.
+    Returns new faces."""
     faces = np.array(faces, dtype=np.int64, copy=True)
     n = len(faces)
     if n == 0:
@@ -57,11 +62,14 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
         return (a == u and b == v) or (b == u and c == v) or (c == u and a == v)
 
     seen = np.zeros(n, dtype=bool)
+    bodies = []
     for root in range(n):
         if seen[root]:
             continue
         seen[root] = True
         queue = [root]
+        body = [root]
+        bodies.append(body)
         while queue:
             f = queue.pop(0)
             for g, u, v in sorted(adj[f]):
@@ -72,10 +80,12 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
                     faces[g] = faces[g][::-1]
                 seen[g] = True
                 queue.append(g)
+                body.append(g)
     tri = verts[faces].astype(np.float64)
-    volume = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])).sum() / 6.0
-    if volume < 0:
-        faces = faces[:, ::-1].copy()
+    signed6 = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2]))      # 6 x signed tetrahedron volume per face
+    for body in bodies:
+        if len(body) > 1 and signed6[body].sum() < 0:
+            faces[body] = faces[body][:, ::-1]
     return faces
 
 

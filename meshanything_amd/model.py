@@ -21,6 +21,7 @@ weights), `.codebook_size`, `.codebook_dim`, `.n_max_triangles` (meshanything.py
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Mapping, Optional
 
 import torch
@@ -118,6 +119,12 @@ class MeshAnything(torch.nn.Module):
         self.cond_dim = self.cfg.enc_width
         self.max_length = self.cfg.n_max_faces * self.face_per_token + 2 + self.cond_length
         self.bos_token_id, self.eos_token_id, self.pad_token_id = BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID
+        # sampling randomness: the reference seeds torch once (`set_seed(args.seed)`, main.py:129-133) and its CUDA RNG then
+        # advances from batch to batch and differs per rank.  Here the sampler draws from a counter-hashed uniform stream
+        # keyed by (seed, row, step), so every forward() call gets its own stream seed derived from (args.seed, rank, call #).
+        self._seed = int(getattr(args, "seed", 0))
+        self._rank = int(os.environ.get("RANK", "0"))
+        self._calls = 0
         self.eval()
 
     # ---- weights -----------------------------------------------------------------------------------------------
@@ -146,12 +153,22 @@ class MeshAnything(torch.nn.Module):
     def get_codes(self, indices: torch.Tensor) -> torch.Tensor:
         return self.engine.get_codes(indices)
 
-    @torch.no_grad()
-    def forward(self, pc_normal: torch.Tensor, sampling: bool = False) -> torch.Tensor:
-        """(B, 4096, 6) -> (B, n_max_triangles, 3, 3) fp32, NaN rows = invalid faces (meshanything.py:134-176): one library call."""
-        return self.engine.forward(pc_normal, sampling=bool(sampling))["coords"]
+    def _next_stream_seed(self) -> int:
+        """splitmix64 of (args.seed, rank, number of forward() calls so far): reproducible, distinct per call and per rank."""
+        z = (self._seed * 0x9E3779B97F4A7C15 + self._rank * 0xD1B54A32D192ED03 + self._calls * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        self._calls += 1
+        return z ^ (z >> 31)
 
     @torch.no_grad()
-    def forward_detailed(self, pc_normal: torch.Tensor, sampling: bool = False, **kw) -> Dict[str, object]:
+    def forward(self, pc_normal: torch.Tensor, sampling: bool = False, seed: Optional[int] = None) -> torch.Tensor:
+        """(B, 4096, 6) -> (B, n_max_triangles, 3, 3) fp32, NaN rows = invalid faces (meshanything.py:134-176): one library call.
+        `seed` (optional) pins the sampler's uniform stream for this call; by default it advances from call to call."""
+        return self.forward_detailed(pc_normal, sampling, seed=seed)["coords"]
+
+    @torch.no_grad()
+    def forward_detailed(self, pc_normal: torch.Tensor, sampling: bool = False, seed: Optional[int] = None, **kw) -> Dict[str, object]:
         """forward() plus the intermediate tensors (tokens, lengths, ids, latents) for tests and tooling."""
-        return self.engine.forward(pc_normal, sampling=bool(sampling), **kw)
+        s = self._next_stream_seed() if seed is None else int(seed)
+        return self.engine.forward(pc_normal, sampling=bool(sampling), seed=s, **kw)

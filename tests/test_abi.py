@@ -103,3 +103,23 @@ def test_product_path_fails_loudly_without_a_gpu(lib):
     import re
     for f in pathlib.Path(REPO, "meshanything_amd").rglob("*.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), flags=re.M), f
+
+
+def test_stale_library_is_detected(lib, tmp_path, monkeypatch):
+    """build.py hashes every file the library is compiled from (csrc/*.hip, csrc/*.hpp -- gemm_decode.hpp included -- and
+    the public header): an edit to any of them makes needs_build() true and makes _lib.load() refuse the stale .so."""
+    import shutil
+    from meshanything_amd import build as B
+    names = {os.path.basename(f) for f in B.source_files()}
+    assert {"engine.hip", "gemm_decode.hpp", "gemv.hpp", "attn_decode.hpp", "meshanything_amd.h"} <= names
+    assert not B.needs_build()                                       # the fixture just loaded a matching library
+    csrc = tmp_path / "csrc"
+    shutil.copytree(B.CSRC, csrc)
+    monkeypatch.setattr(B, "CSRC", str(csrc))
+    assert not B.needs_build()                                       # same bytes elsewhere: same hash
+    with open(csrc / "gemm_decode.hpp", "a") as f:
+        f.write("// edited\n")
+    assert B.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(ImportError, match="built from different sources"):
+        _lib.load()

@@ -8,6 +8,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
+from conftest import cached_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -52,7 +53,7 @@ class Env:
         from meshanything_amd.engine import Engine
         from oracle.meshanything_oracle import Oracle
         self.cfg, self.policy = cfg, policy
-        self.sd = synthetic_state_dict(cfg)
+        self.sd = cached_state_dict(cfg)
         self.oracle = Oracle(cfg, self.sd, policy)
         self.engine = Engine(cfg)
         self.engine.load_weights(self.sd.items())
@@ -206,7 +207,7 @@ def test_large_batches_all_mfma_tile_counts(B):
     cfg = MAConfig.tiny(dtype=DTYPE_BF16, max_batch=64)
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, "bf16"
-    env.sd = synthetic_state_dict(cfg)
+    env.sd = cached_state_dict(cfg)
     env.oracle = Oracle(cfg, env.sd, "bf16")
     env.engine = Engine(cfg)
     env.engine.load_weights(env.sd.items())
@@ -357,7 +358,7 @@ def full(request):
     cfg = MAConfig.full(dtype=POLICIES[request.param], max_batch=6)
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, request.param
-    env.sd = synthetic_state_dict(cfg)
+    env.sd = cached_state_dict(cfg)
     env.oracle = Oracle(cfg, env.sd, request.param)
     env.engine = Engine(cfg)
     env.engine.load_weights(env.sd.items())
@@ -473,7 +474,7 @@ def test_v2_scale_1600_faces(golden_dir):
     assert cfg.max_seq == 14659 and cfg.max_new_tokens == 14402
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, "bf16"
-    env.sd = synthetic_state_dict(cfg)
+    env.sd = cached_state_dict(cfg)
     env.oracle = Oracle(cfg, env.sd, "bf16")
     env.engine = Engine(cfg)
     env.engine.load_weights(env.sd.items())

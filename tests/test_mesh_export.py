@@ -49,3 +49,19 @@ def test_fix_normals_makes_a_scrambled_tetrahedron_consistent_and_outward():
     f2 = fix_normals(v, two)
     e01 = [(f[i], f[(i + 1) % 3]) for f in f2 for i in range(3) if {f[i], f[(i + 1) % 3]} == {0, 1}]
     assert len(e01) == 2 and e01[0] == e01[1][::-1]
+
+
+def test_fix_normals_orients_every_body_on_its_own():
+    """Two tetrahedra far apart, one wound outward and one inward: trimesh's fix_normals resolves multibody to
+    body_count > 1 and fixes each connected body by its own signed volume; a single global flip would leave one inverted."""
+    v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    good = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
+    v = np.concatenate([v1, v1 * 3 + 10])                        # the second body is 27x larger: it dominates the total volume
+    faces = np.concatenate([good[:, ::-1], good + 4])            # small body inverted, big body fine: total volume > 0
+    fixed = fix_normals(v, faces)
+    assert abs(_signed_volume(v, fixed[:4]) - 1 / 6) < 1e-9
+    assert _signed_volume(v, fixed[4:]) > 0
+    faces = np.concatenate([good, (good + 4)[:, ::-1]])          # big body inverted: total volume < 0, the small one must stay
+    fixed = fix_normals(v, faces)
+    assert abs(_signed_volume(v, fixed[:4]) - 1 / 6) < 1e-9 and np.array_equal(fixed[:4], good)
+    assert _signed_volume(v, fixed[4:]) > 0
