@@ -81,7 +81,11 @@ template <typename KT, bool ROWWAVE>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
                                                           const KT* __restrict__ vc, int max_seq, const DecState* st,
                                                           int len_override, int round_q, float* __restrict__ ws,
-                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch) {
+                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch, PfDesc pf) {
+    if (blockIdx.x >= ATTN_NCHUNK) {         // prefetch-only blocks (common.hpp): grid.x = ATTN_NCHUNK + pf.blocks / heads
+        if (blockIdx.z == 0) pf_run(pf, (int)((blockIdx.x - ATTN_NCHUNK) * gridDim.y + blockIdx.y), 0);
+        return;
+    }
     constexpr int EPL = 16 / sizeof(KT);     // elements per lane per 16-byte load
     constexpr int LPP = 64 / EPL;            // lanes per position
     constexpr int PPW = 64 / LPP;            // positions per wave-load
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     constexpr int RSH = ROWWAVE ? 5 : 7;                  // positions per round: 32 per wave | 128 per block
     const int woff = ROWWAVE ? 0 : w * 32;
     const int slot = lane / LPP, dsub = lane % LPP;
-    if (trace && threadIdx.x == 0) trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    if (trace && threadIdx.x == 0) trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     // batch row (grid.z): its query, its cache planes, its partials, its state
     q += (size_t)brow * q_stride;
     kc += (size_t)brow * kv_row_stride;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         }
     }
 
-    if (trace && threadIdx.x == 0) trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (trace && threadIdx.x == 0) trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     // merge the NS per-slot states of this block -> one partial per (head, chunk); an empty chunk publishes (m=-1e30, l=0, o=0).
     // Two levels, all 256 threads: thread (quarter qd, dim) folds NS/4 states, then wave 0 folds the four quarters.
     __shared__ float sm[NS], sl[NS], so[NS][64];
@@ -239,22 +243,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         float* op = ws + (size_t)H * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
         if (lane == 0) { ml[0] = M; ml[1] = L; }
         op[lane] = O;
-        if (trace && threadIdx.x == 0) trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (trace && threadIdx.x == 0) trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
 template <typename KT>
 inline hipError_t launch_attn_decode(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
                                      int round_q, float* workspace, hipStream_t s, unsigned long long* trace = nullptr, int batch = 1,
-                                     int q_stride = 0, size_t kv_row_stride = 0, bool rowwave = false) {
+                                     int q_stride = 0, size_t kv_row_stride = 0, bool rowwave = false, PfDesc pf = PfDesc{}) {
+    // prefetch blocks come in whole grid.x columns of H blocks
+    const int pfx = pf.blocks > 0 ? (pf.blocks + H - 1) / H : 0;
+    pf.blocks = pfx * H;
     // rowwave: only with the batched MFMA decode path (the row-parallel GEMV path keeps every row's arithmetic identical
     // to a batch-1 run, including the attention's merge order)
     if (rowwave && batch >= 4)
-        hipLaunchKernelGGL((attn_decode_kernel<KT, true>), dim3(ATTN_NCHUNK, H, (batch + 3) / 4), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
-                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
+        hipLaunchKernelGGL((attn_decode_kernel<KT, true>), dim3(ATTN_NCHUNK + pfx, H, (batch + 3) / 4), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch, pf);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<KT, false>), dim3(ATTN_NCHUNK, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
-                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
+        hipLaunchKernelGGL((attn_decode_kernel<KT, false>), dim3(ATTN_NCHUNK + pfx, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch, pf);
     return hipGetLastError();
 }
 

@@ -199,37 +199,20 @@ __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
         }
     }
     if constexpr (PRO == PRO_LN) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
-        s = wave_sum(s);
-        if (lane == 0) red[w] = s;
-        __syncthreads();
-        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)K;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            if (tid + 256 * j < nq) {
-                const float d0 = xv[j].x - mean, d1 = xv[j].y - mean, d2 = xv[j].z - mean, d3 = xv[j].w - mean;
-                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-        }
-        q = wave_sum(q);
-        if (lane == 0) red[4 + w] = q;
-        __syncthreads();
-        const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)K + a.ln_eps);
+        // element 0 of the (summed) row, computed by every thread exactly as thread 0 computes it: the statistics' shift
+        const float* x = a.x + (size_t)b * a.x_stride;
+        float x0 = x[0];
+        for (int p = 1; p < a.nparts; ++p) x0 += x[(size_t)p * a.B * a.x_stride];
+        if (a.bias) x0 += a.bias[0];
+        if (a.res) x0 += a.res[(size_t)b * a.res_stride];
+        f32x4 gv[NCH], bv[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = tid + 256 * j;
-            if (idx < nq) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + idx * 4);
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.ln_b + idx * 4);
-                xv[j].x = (xv[j].x - mean) * rstd * g.x + bb.x;
-                xv[j].y = (xv[j].y - mean) * rstd * g.y + bb.y;
-                xv[j].z = (xv[j].z - mean) * rstd * g.z + bb.z;
-                xv[j].w = (xv[j].w - mean) * rstd * g.w + bb.w;
-            }
+            gv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(a.ln_g + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(a.ln_b + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        ln_block_onepass<NCH>(xv, gv, bv, x0, tid, nq, K, a.ln_eps, red);
     }
     constexpr int NJ = PRO == PRO_ATTN ? 1 : NCH;
 #pragma unroll

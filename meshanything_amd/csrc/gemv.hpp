@@ -52,8 +52,10 @@ struct GemvArgs {
     int x_stride, y_stride, res_stride, xn_stride, part_stride; size_t kv_row_stride; size_t attn_ws_stride;
     // diagnostics (ma_trace_decode): wave 0 of block b stores the 100 MHz real-time counter at four points into trace[b*4..]
     unsigned long long* trace;
+    // operand prefetch for a later launch (common.hpp): blocks [ncompute, ncompute + pf.blocks) of grid.y == 0
+    PfDesc pf; int ncompute;
 };
-#define MA_TRACE(tr, slot) do { if ((tr) && threadIdx.x == 0) (tr)[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MA_TRACE(tr, slot) do { if ((tr) && threadIdx.x == 0) (tr)[(blockIdx.y * (gridDim.x - a.pf.blocks) + blockIdx.x) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 template <typename WT> struct WTraits;
 template <> struct WTraits<float>  { static constexpr int VEC = 4; };
@@ -85,6 +87,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ float red[8];
     __shared__ float lv[16];
+    if (a.pf.blocks > 0 && (int)blockIdx.x >= a.ncompute) {            // prefetch-only blocks (block-uniform branch)
+        if (blockIdx.y == 0) pf_run(a.pf, (int)blockIdx.x - a.ncompute, a.pf.dyn_unit ? a.st->pos : 0);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int grp = w / KSPLIT, wk = w % KSPLIT;
     const int row0 = blockIdx.x * RPB + grp * RPW;       // first row of this wave's group
@@ -140,6 +146,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         constexpr int NCH = (KC / 4 + 255) / 256;
         f32x4 xv[NCH], gv[PRO == PRO_LN ? NCH : 1], bv[PRO == PRO_LN ? NCH : 1];
         f32x4 pml[PRO == PRO_ATTN ? ATTN_NCHUNK / 2 : 1], po[PRO == PRO_ATTN ? ATTN_NCHUNK : 1];
+        float x0 = 0.f;                      // PRO_LN: shift of the one-pass statistics (element 0 of the row, a broadcast load)
+        if constexpr (PRO == PRO_LN) x0 = x[0];
         if constexpr (PRO == PRO_ATTN) {
             static_assert(PRO != PRO_ATTN || NCH == 1, "PRO_ATTN fast path: K <= 1024");
             const int k = tid * 4, h = k >> 6, d0 = k & 63;
@@ -171,32 +179,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         load_epilogue_operands();
         // ---- (3) prologue math, result parked in LDS (rounded to the policy dtype) ------------------------------------
         if constexpr (PRO == PRO_LN) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
-            s = wave_sum(s);
-            if (lane == 0) red[w] = s;
-            __syncthreads();
-            const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)K;
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                if (tid + 256 * j < KC / 4) {
-                    const float d0 = xv[j].x - mean, d1 = xv[j].y - mean, d2 = xv[j].z - mean, d3 = xv[j].w - mean;
-                    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-                }
-            }
-            q = wave_sum(q);
-            if (lane == 0) red[4 + w] = q;
-            __syncthreads();
-            const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)K + a.ln_eps);
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                xv[j].x = (xv[j].x - mean) * rstd * gv[j].x + bv[j].x;
-                xv[j].y = (xv[j].y - mean) * rstd * gv[j].y + bv[j].y;
-                xv[j].z = (xv[j].z - mean) * rstd * gv[j].z + bv[j].z;
-                xv[j].w = (xv[j].w - mean) * rstd * gv[j].w + bv[j].w;
-            }
+            ln_block_onepass<NCH>(xv, gv, bv, x0, tid, KC / 4, K, a.ln_eps, red);
         } else if constexpr (PRO == PRO_ATTN) {
             xv[0] = attn_partials_merge(pml, po);
         }
@@ -363,15 +346,18 @@ inline void launch_gemv_pro(const GemvArgs& a, int pro, dim3 grid, hipStream_t s
 }
 
 template <typename WT>
-inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s, int batch = 1) {
+inline hipError_t launch_gemv(const GemvArgs& a_in, hipStream_t s, int batch = 1) {
     constexpr int VEC = WTraits<WT>::VEC;
-    if (a.K % VEC != 0) return hipErrorInvalidValue;
+    if (a_in.K % VEC != 0) return hipErrorInvalidValue;
+    GemvArgs a = a_in;
     const int pro = a.attn_ws ? PRO_ATTN : (a.ln_g ? PRO_LN : PRO_PLAIN);
     if (pro == PRO_ATTN && (a.K != a.attn_heads * 64)) return hipErrorInvalidValue;
     GemvShape g = gemv_shape<WT>(a.N, a.K);
     if (pro == PRO_ATTN && g.lpl > 0 && a.K > 1024) g = GemvShape{1, 0, 1};       // wide merges take the generic path
     const int rpb = (4 / g.ksplit) * g.rpw;
-    const dim3 grid((a.N + rpb - 1) / rpb, batch);
+    a.ncompute = (a.N + rpb - 1) / rpb;
+    if (a.pf.blocks < 0 || (a.pf.dyn_unit && !a.st)) return hipErrorInvalidValue;
+    const dim3 grid(a.ncompute + a.pf.blocks, batch);
 #define MA_GEMV_CASE(KS, LP, RW) if (g.ksplit == KS && g.lpl == LP && g.rpw == RW) { launch_gemv_pro<WT, KS, LP, RW>(a, pro, grid, s); return hipGetLastError(); }
     MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(1, 2, 4) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
     MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)
