@@ -81,11 +81,7 @@ template <typename KT, bool ROWWAVE>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
                                                           const KT* __restrict__ vc, int max_seq, const DecState* st,
                                                           int len_override, int round_q, float* __restrict__ ws,
-                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch, PfDesc pf) {
-    if (blockIdx.x >= ATTN_NCHUNK) {         // prefetch-only blocks (common.hpp): grid.x = ATTN_NCHUNK + pf.blocks / heads
-        if (blockIdx.z == 0) pf_run(pf, (int)((blockIdx.x - ATTN_NCHUNK) * gridDim.y + blockIdx.y), 0);
-        return;
-    }
+                                                          unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch) {
     constexpr int EPL = 16 / sizeof(KT);     // elements per lane per 16-byte load
     constexpr int LPP = 64 / EPL;            // lanes per position
     constexpr int PPW = 64 / LPP;            // positions per wave-load
@@ -250,18 +246,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 template <typename KT>
 inline hipError_t launch_attn_decode(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
                                      int round_q, float* workspace, hipStream_t s, unsigned long long* trace = nullptr, int batch = 1,
-                                     int q_stride = 0, size_t kv_row_stride = 0, bool rowwave = false, PfDesc pf = PfDesc{}) {
-    // prefetch blocks come in whole grid.x columns of H blocks
-    const int pfx = pf.blocks > 0 ? (pf.blocks + H - 1) / H : 0;
-    pf.blocks = pfx * H;
+                                     int q_stride = 0, size_t kv_row_stride = 0, bool rowwave = false) {
     // rowwave: only with the batched MFMA decode path (the row-parallel GEMV path keeps every row's arithmetic identical
     // to a batch-1 run, including the attention's merge order)
     if (rowwave && batch >= 4)
-        hipLaunchKernelGGL((attn_decode_kernel<KT, true>), dim3(ATTN_NCHUNK + pfx, H, (batch + 3) / 4), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
-                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch, pf);
+        hipLaunchKernelGGL((attn_decode_kernel<KT, true>), dim3(ATTN_NCHUNK, H, (batch + 3) / 4), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
     else
-        hipLaunchKernelGGL((attn_decode_kernel<KT, false>), dim3(ATTN_NCHUNK + pfx, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
-                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch, pf);
+        hipLaunchKernelGGL((attn_decode_kernel<KT, false>), dim3(ATTN_NCHUNK, H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                           reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, workspace, trace, q_stride, kv_row_stride, batch);
     return hipGetLastError();
 }
 

@@ -131,43 +131,6 @@ __device__ inline u32x4 ld_stream16(const void* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 
-// ---- operand prefetch into the Infinity Cache ---------------------------------------------------------------------------
-// A batch-1 decode launch is a latency chain: its own HBM stream is active for a quarter of its
-// life, and a later launch cannot start its loads before the kernel boundary.  The 256 MB memory-side Infinity Cache (MALL)
-// survives kernel boundaries, so every launch carries a few extra blocks that do nothing but TOUCH the operand of a LATER
-// launch (one dword per 128-byte line, default cache policy): HBM streams in the background of the latency-bound work, and
-// the later launch finds its weights / KV rows on die.  The descriptor covers `nbase` base pointers x `nseg` segments of
-// `seg_bytes` (or, dyn != 0, of pos * dyn_unit bytes: the cached positions of a KV plane) `seg_stride` bytes apart.
-struct PfDesc {
-    const char* base0; const char* base1;
-    unsigned long long seg_bytes, seg_stride;
-    int nbase, nseg, dyn_unit, blocks;
-    unsigned* sink;          // always null at run time: keeps the loads alive
-};
-__device__ __forceinline__ void pf_run(const PfDesc d, int pf_block, int pos) {      // by value: a reference would pin the kernel's argument struct in scratch
-    const unsigned long long seg_bytes = d.dyn_unit ? (unsigned long long)pos * d.dyn_unit : d.seg_bytes;
-    const unsigned lines_per_seg = (unsigned)((seg_bytes + 127) >> 7);
-    const unsigned total = lines_per_seg * (unsigned)(d.nseg * d.nbase);
-    const unsigned G = (unsigned)d.blocks * 256u;
-    unsigned acc = 0;
-    for (unsigned i0 = (unsigned)pf_block * 256u + threadIdx.x; i0 < total; i0 += 8u * G) {
-        unsigned v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned i = i0 + (unsigned)u * G;
-            v[u] = 0;
-            if (i < total) {
-                const unsigned seg = i / lines_per_seg, line = i - seg * lines_per_seg;
-                const unsigned b = seg / (unsigned)d.nseg, s = seg - b * (unsigned)d.nseg;
-                v[u] = *reinterpret_cast<const unsigned*>((b ? d.base1 : d.base0) + (unsigned long long)s * d.seg_stride + ((unsigned long long)line << 7));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= v[u];
-    }
-    if (d.sink) *d.sink = acc;
-}
-
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

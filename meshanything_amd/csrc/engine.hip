@@ -102,8 +102,6 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
-    int opt_pf_dist = 0;             // operand prefetch into the Infinity Cache: launch i touches the operand of launch i + pf_dist (0 = off)
-    int opt_pf_kv = 1;               // ... including the cached K/V rows of the attention launch
     bf16_t *d_xb = nullptr, *d_ffb = nullptr;      // bf16 activations of the batched path: [max_batch][hidden], [max_batch][ffn]
     float *d_ks_o = nullptr, *d_ks_f = nullptr;    // split-K partials of out_proj / fc2: [4][max_batch][hidden]
 
@@ -251,49 +249,6 @@ struct StepTimer {                    // launch filter (ma_profile_decode) / in-
 // buffer, its own KV planes, its own DecState record and its own output token row; the weights are shared.
 struct Rows { int r0 = 0, B = 1; };
 
-// ---- operand prefetch (common.hpp PfDesc): launch order of one batch-1 decode step is
-//   0 embed | 1 + 5 l + {0 qkv, 1 attention, 2 out_proj, 3 fc1, 4 fc2} | 1 + 5 L lm_head | 2 + 5 L pick
-// and launch i carries extra blocks that touch the operand of launch i + pf_dist (wrapping into the next step).
-int step_launches(ma_engine* e) { return 3 + 5 * e->cfg.layers; }
-
-PfDesc weights_pf(const void* w, size_t bytes) {
-    PfDesc d{};
-    d.base0 = reinterpret_cast<const char*>(w); d.nbase = 1; d.nseg = 1; d.seg_bytes = bytes; d.seg_stride = 0;
-    const size_t lines = (bytes + 127) / 128;
-    d.blocks = (int)std::min<size_t>(128, std::max<size_t>(1, (lines + 2047) / 2048));       // 8 lines per thread
-    return d;
-}
-
-PfDesc operand_pf(ma_engine* e, int op, Rows rw) {
-    const ma_config& c = e->cfg;
-    const int n = step_launches(e);
-    op = ((op % n) + n) % n;
-    const size_t esz = e->bf16 ? 2 : 4, H = c.hidden;
-    if (op == 0) return weights_pf(e->P(DEC + "input_layer.weight"), H * (size_t)c.codebook_dim * esz);
-    if (op == n - 1) return PfDesc{};                                                          // pick: logits are on die already
-    if (op == n - 2) return weights_pf(e->P("transformer.lm_head.weight"), (size_t)e->V * H * esz);
-    const int l = (op - 1) / 5, k = (op - 1) % 5;
-    const DecLayerPtrs& w = e->dl[l];
-    switch (k) {
-        case 0: return weights_pf(w.qkv_w, 3 * H * H * esz);
-        case 2: return weights_pf(w.o_w, H * H * esz);
-        case 3: return weights_pf(w.fc1_w, (size_t)c.ffn * H * esz);
-        case 4: return weights_pf(w.fc2_w, (size_t)c.ffn * H * esz);
-        default: break;
-    }
-    // attention: the cached rows [0, pos) of every head's K and V plane of layer l (pos read from the device state)
-    PfDesc d{};
-    if (!e->opt_pf_kv || rw.B != 1) return d;
-    d.base0 = e->kplane(rw.r0, l); d.base1 = e->vplane(rw.r0, l); d.nbase = 2; d.nseg = c.heads;
-    d.seg_stride = (size_t)e->maxseq * 64 * esz; d.dyn_unit = (int)(64 * esz);
-    d.blocks = 64;
-    return d;
-}
-PfDesc prefetch_for(ma_engine* e, int op, Rows rw) {
-    if (e->opt_pf_dist <= 0 || rw.B != 1) return PfDesc{};
-    return operand_pf(e, op + e->opt_pf_dist, rw);
-}
-
 GemvArgs gemv_base(ma_engine* e, Rows rw) {
     GemvArgs a{};
     a.round_x = e->bf16 ? 1 : 0;
@@ -418,16 +373,13 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.x_stride = H; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? h0 : nullptr; a.xn_stride = H;
         a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems;
         a.H = H; a.max_seq = e->maxseq;
-        a.pf = prefetch_for(e, 1 + 5 * l + 0, rw);
         a.trace = tm.trace_slot(1, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
     }
     if (tm.on(1)) {
         unsigned long long* tr = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
-        PfDesc pf = prefetch_for(e, 1 + 5 * l + 1, rw);
-        if (pf.dyn_unit) pf = PfDesc{};                       // (the attention launch only prefetches weights)
-        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems, false, pf)
-                               : launch_attn_decode<float>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 0, part, s, tr, B, H, kv_row_elems, false, pf);
+        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems)
+                               : launch_attn_decode<float>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 0, part, s, tr, B, H, kv_row_elems);
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
     }
     {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
@@ -435,7 +387,6 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         // the attention output is never materialised: this GEMV's prologue merges the split-KV partials
         a.W = w.o_w; a.bias = w.o_b; a.x = nullptr; a.attn_ws = part; a.attn_ws_stride = attn_workspace_floats(c.heads); a.attn_heads = c.heads;
         a.res = resid; a.res_stride = H; a.y = y1; a.y_stride = H; a.N = H; a.K = H;
-        a.pf = prefetch_for(e, 1 + 5 * l + 2, rw);
         a.trace = tm.trace_slot(3, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
     }
@@ -443,22 +394,19 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         GemvArgs a = gemv_base(e, rw);
         a.W = w.fc1_w; a.bias = w.fc1_b; a.x = y1; a.x_stride = H; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = h1; a.xn_stride = H;
         a.y = ffn; a.y_stride = c.ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
-        a.pf = prefetch_for(e, 1 + 5 * l + 3, rw);
         a.trace = tm.trace_slot(4, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
     }
     {   // y2 = h1 + W2 f + b2
         GemvArgs a = gemv_base(e, rw);
         a.W = w.fc2_w; a.bias = w.fc2_b; a.x = ffn; a.x_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H; a.N = H; a.K = c.ffn;
-        a.pf = prefetch_for(e, 1 + 5 * l + 4, rw);
         a.trace = tm.trace_slot(5, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
     }
 }
 
-void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw, bool in_step = false) {
+void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw) {
     GemvArgs a = gemv_base(e, rw);
-    if (in_step) a.pf = prefetch_for(e, step_launches(e) - 2, rw);
     a.W = e->P("transformer.lm_head.weight"); a.x = x; a.x_stride = x_stride; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
     a.y = e->d_logits + (size_t)rw.r0 * e->V; a.y_stride = e->V; a.N = e->V; a.K = e->cfg.hidden; a.epi = EPI_LMHEAD;
     a.part_val = e->d_pval + (size_t)rw.r0 * e->V; a.part_idx = e->d_pidx + (size_t)rw.r0 * e->V; a.part_stride = e->V;
@@ -486,7 +434,6 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         a.epi = EPI_EMBED; a.codebook = e->PF(DEC + "quantize_codebooks"); a.extra = e->PF(DEC + "extra_embeds.weight");
         a.tokpos = e->PF(DEC + "token_embed_positions.weight"); a.cond = e->PF(DEC + "cond_embed.weight");
         a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
-        if (!use_mfma_decode(e, rw.B)) a.pf = prefetch_for(e, 0, rw);
         a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, rw.B);
     }
@@ -498,7 +445,7 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
             if (l == 0) enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw);
             else enqueue_layer(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm, rw);
         }
-        enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw, true);
+        enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw);
     }
     enqueue_pick(e, s, tm, rw);
 }
@@ -850,8 +797,6 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
-        else if (n == "pf_dist") { if (value < 0 || value > 16) throw MaError(MA_ERR_INVALID, "pf_dist must be in [0,16]"); e->opt_pf_dist = (int)value; drop_graphs(e); }
-        else if (n == "pf_kv") { e->opt_pf_kv = value ? 1 : 0; drop_graphs(e); }
         else if (n == "gemv_rpw") {
             if (value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1, 2 or 4");
             gemv_rpw_big() = (int)value;

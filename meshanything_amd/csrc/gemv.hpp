@@ -52,10 +52,8 @@ struct GemvArgs {
     int x_stride, y_stride, res_stride, xn_stride, part_stride; size_t kv_row_stride; size_t attn_ws_stride;
     // diagnostics (ma_trace_decode): wave 0 of block b stores the 100 MHz real-time counter at four points into trace[b*4..]
     unsigned long long* trace;
-    // operand prefetch for a later launch (common.hpp): blocks [ncompute, ncompute + pf.blocks) of grid.y == 0
-    PfDesc pf; int ncompute;
 };
-#define MA_TRACE(tr, slot) do { if ((tr) && threadIdx.x == 0) (tr)[(blockIdx.y * (gridDim.x - a.pf.blocks) + blockIdx.x) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MA_TRACE(tr, slot) do { if ((tr) && threadIdx.x == 0) (tr)[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 template <typename WT> struct WTraits;
 template <> struct WTraits<float>  { static constexpr int VEC = 4; };
@@ -87,10 +85,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ float red[8];
     __shared__ float lv[16];
-    if (a.pf.blocks > 0 && (int)blockIdx.x >= a.ncompute) {            // prefetch-only blocks (block-uniform branch)
-        if (blockIdx.y == 0) pf_run(a.pf, (int)blockIdx.x - a.ncompute, a.pf.dyn_unit ? a.st->pos : 0);
-        return;
-    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int grp = w / KSPLIT, wk = w % KSPLIT;
     const int row0 = blockIdx.x * RPB + grp * RPW;       // first row of this wave's group
@@ -346,18 +340,15 @@ inline void launch_gemv_pro(const GemvArgs& a, int pro, dim3 grid, hipStream_t s
 }
 
 template <typename WT>
-inline hipError_t launch_gemv(const GemvArgs& a_in, hipStream_t s, int batch = 1) {
+inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s, int batch = 1) {
     constexpr int VEC = WTraits<WT>::VEC;
-    if (a_in.K % VEC != 0) return hipErrorInvalidValue;
-    GemvArgs a = a_in;
+    if (a.K % VEC != 0) return hipErrorInvalidValue;
     const int pro = a.attn_ws ? PRO_ATTN : (a.ln_g ? PRO_LN : PRO_PLAIN);
     if (pro == PRO_ATTN && (a.K != a.attn_heads * 64)) return hipErrorInvalidValue;
     GemvShape g = gemv_shape<WT>(a.N, a.K);
     if (pro == PRO_ATTN && g.lpl > 0 && a.K > 1024) g = GemvShape{1, 0, 1};       // wide merges take the generic path
     const int rpb = (4 / g.ksplit) * g.rpw;
-    a.ncompute = (a.N + rpb - 1) / rpb;
-    if (a.pf.blocks < 0 || (a.pf.dyn_unit && !a.st)) return hipErrorInvalidValue;
-    const dim3 grid(a.ncompute + a.pf.blocks, batch);
+    const dim3 grid((a.N + rpb - 1) / rpb, batch);
 #define MA_GEMV_CASE(KS, LP, RW) if (g.ksplit == KS && g.lpl == LP && g.rpw == RW) { launch_gemv_pro<WT, KS, LP, RW>(a, pro, grid, s); return hipGetLastError(); }
     MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(1, 2, 4) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
     MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)
