@@ -218,6 +218,18 @@ MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_tim
 MA_API int  ma_trace_decode(ma_engine *e, int kv_len, uint64_t *host_out, int max_launches, int max_blocks, int32_t *kinds,
                             int32_t *blocks, int32_t *n_launches, void *stream);
 
+/* ---- persistent decode step (csrc/persist.hpp): the whole batch-1 greedy step as ONE resident launch instead of the
+ * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()
+ * and the call is batch 1 / greedy, otherwise the chain runs.  replaces: the same reference calls as ma_generate's steps
+ * (shape_opt.py:318-364,403-410,155; meshanything.py:143-151). */
+MA_API int  ma_engine_persist_available(ma_engine *e);
+/* host_out: 256 * 320 uint64 (comm wave of every workgroup: start, then per edge {sweep start, gather done}, end; 100 MHz
+ * ticks), followed by 256 * 512 uint64 (compute wave 0: per weight op {input ready, weights landed, dots done, published},
+ * per attention {partial published, partials gathered, merged output published}) */
+MA_API int  ma_persist_trace(ma_engine *e, int kv_len, uint64_t *host_out, int32_t *n_events, void *stream);
+/* copies the logits of the most recent decode step of batch row `row` (codebook_size + 3 floats) into a device buffer */
+MA_API int  ma_engine_read_logits(ma_engine *e, int row, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

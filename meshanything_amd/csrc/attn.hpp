@@ -156,13 +156,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 typedef __bf16 attn_bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int AM_LD = 72;                // bf16 elements per LDS row: 64 + 8 pad (144-byte rows keep ds_read_b128 aligned)
 
-__device__ inline float row_max16(float v) {
-    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
-    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
-    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
-    return v;
-}
 
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AM_LD];

@@ -74,6 +74,95 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 }
 
 // ---- producer side ---------------------------------------------------------------------------------------------------
+// Geometry of one wave-load (shared by the launch-chain kernel below and the persistent decode kernel, persist.hpp): a lane
+// holds EPL elements (16 bytes) of one position, LPP lanes share a position, a wave-load covers PPW positions, a wave owns
+// 32 positions per round (U loads per operand).
+template <typename KT> struct AttnGeom {
+    static constexpr int EPL = 16 / sizeof(KT), LPP = 64 / EPL, PPW = 64 / LPP, U = 32 / PPW, NS = 4 * PPW;
+};
+template <typename KT> __device__ __forceinline__ void attn_unpack(const u32x4& r, float (&f)[16 / sizeof(KT)]) {
+    if constexpr (sizeof(KT) == 4) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    } else {
+        f[0] = bf_lo(r.x); f[1] = bf_hi(r.x); f[2] = bf_lo(r.y); f[3] = bf_hi(r.y);
+        f[4] = bf_lo(r.z); f[5] = bf_hi(r.z); f[6] = bf_lo(r.w); f[7] = bf_hi(r.w);
+    }
+}
+// online-softmax state of one position slot (the LPP lanes of a slot hold the same m, l and their own EPL dims of o)
+template <typename KT> struct AttnSlotState { float m, l, o[16 / sizeof(KT)]; };
+
+// one round: the U positions base + u * PPW of this lane's slot (positions >= end are masked), one rescale per round.
+// OVR: position ovr_pos takes its K / V rows from (ovr_k, ovr_v) instead of the loaded registers (persistent kernel: the
+// newest position has not reached the cache yet).
+template <typename KT, bool OVR>
+__device__ __forceinline__ void attn_round_reduce(AttnSlotState<KT>& st, const float (&qv)[16 / sizeof(KT)], const u32x4 (&kr)[AttnGeom<KT>::U],
+                                                  const u32x4 (&vr)[AttnGeom<KT>::U], int base, int end, int ovr_pos, const u32x4& ovr_k,
+                                                  const u32x4& ovr_v) {
+    using G = AttnGeom<KT>;
+    float d[G::U];
+    float mr = st.m;
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) {
+        float kf[G::EPL];
+        if constexpr (OVR) attn_unpack<KT>(base + u * G::PPW == ovr_pos ? ovr_k : kr[u], kf);
+        else attn_unpack<KT>(kr[u], kf);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) t = fmaf(qv[e], kf[e], t);
+        t = group_sum<G::LPP>(t) * 0.125f;                 // 1/sqrt(64)
+        d[u] = (base + u * G::PPW < end) ? t : -1e30f;
+        mr = fmaxf(mr, d[u]);
+    }
+    const float alpha = expf(st.m - mr);                   // one rescale per round
+    st.l *= alpha;
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) st.o[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < G::U; ++u) {
+        float vf[G::EPL];
+        if constexpr (OVR) attn_unpack<KT>(base + u * G::PPW == ovr_pos ? ovr_v : vr[u], vf);
+        else attn_unpack<KT>(vr[u], vf);
+        const float pexp = (base + u * G::PPW < end) ? expf(d[u] - mr) : 0.f;
+        st.l += pexp;
+#pragma unroll
+        for (int e = 0; e < G::EPL; ++e) st.o[e] = fmaf(pexp, vf[e], st.o[e]);
+    }
+    st.m = mr;
+}
+
+// LDS of the block-level merge: NS slot states, then one state per wave ("quarter")
+template <typename KT> struct AttnMergeLds {
+    float sm[AttnGeom<KT>::NS], sl[AttnGeom<KT>::NS], so[AttnGeom<KT>::NS][64];
+    float qm[4], ql[4], qo[4][64];
+};
+// level 1: wave w folds the NS/4 slot states [w * NS/4, ...) (lane = dim).  Result: (M, L, O[lane]) of the wave's quarter.
+template <typename KT>
+__device__ __forceinline__ void attn_fold_quarter(const AttnMergeLds<KT>& S, int w, int lane, float& M, float& L, float& O) {
+    constexpr int NQ = AttnGeom<KT>::NS / 4;
+    M = -1e30f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) M = fmaxf(M, S.sm[w * NQ + i]);
+    L = 0.f; O = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const float f = expf(S.sm[w * NQ + i] - M);
+        L = fmaf(S.sl[w * NQ + i], f, L);
+        O = fmaf(S.so[w * NQ + i][lane], f, O);
+    }
+}
+// level 2 (one wave): fold the four quarters
+template <typename KT>
+__device__ __forceinline__ void attn_fold_block(const AttnMergeLds<KT>& S, int lane, float& M, float& L, float& O) {
+    M = fmaxf(fmaxf(S.qm[0], S.qm[1]), fmaxf(S.qm[2], S.qm[3]));
+    L = 0.f; O = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float f = expf(S.qm[i] - M);
+        L = fmaf(S.ql[i], f, L);
+        O = fmaf(S.qo[i][lane], f, O);
+    }
+}
+
 // ROWWAVE = false: the 4 waves of a block share one (row, head, chunk) and split its positions (batch 1: every CU works on
 // the one sequence).  ROWWAVE = true (batches of >= 4 rows): each wave owns its own batch row's (head, chunk) -- a quarter
 // of the blocks, no block-level merge, and short caches (a chunk of <= 32 positions) keep all four waves busy.
@@ -82,11 +171,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
                                                           const KT* __restrict__ vc, int max_seq, const DecState* st,
                                                           int len_override, int round_q, float* __restrict__ ws,
                                                           unsigned long long* trace, int q_stride, size_t kv_row_stride, int batch) {
-    constexpr int EPL = 16 / sizeof(KT);     // elements per lane per 16-byte load
-    constexpr int LPP = 64 / EPL;            // lanes per position
-    constexpr int PPW = 64 / LPP;            // positions per wave-load
-    constexpr int U = 32 / PPW;              // loads per lane per operand and round: 32 positions per wave
-    constexpr int NS = 4 * PPW;              // softmax states per block
+    using G = AttnGeom<KT>;
+    constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, U = G::U;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x, h = blockIdx.y, H = gridDim.y;
     const int brow_raw = ROWWAVE ? blockIdx.z * 4 + w : blockIdx.z;
@@ -134,48 +220,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             vr[u] = ld_stream16(vh + (size_t)(p < end ? p : start) * 64);
         }
     };
-    float m = -1e30f, l = 0.f, o[EPL];
+    AttnSlotState<KT> ss;
+    ss.m = -1e30f; ss.l = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+    for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
+    const u32x4 none = {0u, 0u, 0u, 0u};
     auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
-        const int base = start + (r << RSH) + woff + slot;
-        float d[U];
-        float mr = m;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float kf[EPL];
-            if constexpr (sizeof(KT) == 4) {
-                kf[0] = __uint_as_float(kr[u].x); kf[1] = __uint_as_float(kr[u].y); kf[2] = __uint_as_float(kr[u].z); kf[3] = __uint_as_float(kr[u].w);
-            } else {
-                kf[0] = bf_lo(kr[u].x); kf[1] = bf_hi(kr[u].x); kf[2] = bf_lo(kr[u].y); kf[3] = bf_hi(kr[u].y);
-                kf[4] = bf_lo(kr[u].z); kf[5] = bf_hi(kr[u].z); kf[6] = bf_lo(kr[u].w); kf[7] = bf_hi(kr[u].w);
-            }
-            float t = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) t = fmaf(qv[e], kf[e], t);
-            t = group_sum<LPP>(t) * 0.125f;                 // 1/sqrt(64)
-            d[u] = (base + u * PPW < end) ? t : -1e30f;
-            mr = fmaxf(mr, d[u]);
-        }
-        const float alpha = expf(m - mr);                   // one rescale per round
-        l *= alpha;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] *= alpha;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float vf[EPL];
-            if constexpr (sizeof(KT) == 4) {
-                vf[0] = __uint_as_float(vr[u].x); vf[1] = __uint_as_float(vr[u].y); vf[2] = __uint_as_float(vr[u].z); vf[3] = __uint_as_float(vr[u].w);
-            } else {
-                vf[0] = bf_lo(vr[u].x); vf[1] = bf_hi(vr[u].x); vf[2] = bf_lo(vr[u].y); vf[3] = bf_hi(vr[u].y);
-                vf[4] = bf_lo(vr[u].z); vf[5] = bf_hi(vr[u].z); vf[6] = bf_lo(vr[u].w); vf[7] = bf_hi(vr[u].w);
-            }
-            const float pexp = (base + u * PPW < end) ? expf(d[u] - mr) : 0.f;
-            l += pexp;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] = fmaf(pexp, vf[e], o[e]);
-        }
-        m = mr;
+        attn_round_reduce<KT, false>(ss, qv, kr, vr, start + (r << RSH) + woff + slot, end, -1, none, none);
     };
     if (round_q) {
 #pragma unroll
@@ -194,25 +245,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     if (trace && threadIdx.x == 0) trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     // merge the NS per-slot states of this block -> one partial per (head, chunk); an empty chunk publishes (m=-1e30, l=0, o=0).
     // Two levels, all 256 threads: thread (quarter qd, dim) folds NS/4 states, then wave 0 folds the four quarters.
-    __shared__ float sm[NS], sl[NS], so[NS][64];
-    __shared__ float qm[4], ql[4], qo[4][64];
+    __shared__ AttnMergeLds<KT> S;
     const int gs = w * PPW + slot;
-    if (dsub == 0) { sm[gs] = m; sl[gs] = l; }
+    if (dsub == 0) { S.sm[gs] = ss.m; S.sl[gs] = ss.l; }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) so[gs][dsub * EPL + e] = o[e];
+    for (int e = 0; e < EPL; ++e) S.so[gs][dsub * EPL + e] = ss.o[e];
     __syncthreads();
     {
-        constexpr int NQ = NS / 4;
-        float M = -1e30f;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) M = fmaxf(M, sm[w * NQ + i]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const float f = expf(sm[w * NQ + i] - M);
-            L = fmaf(sl[w * NQ + i], f, L);
-            O = fmaf(so[w * NQ + i][lane], f, O);
-        }
+        float M, L, O;
+        attn_fold_quarter<KT>(S, w, lane, M, L, O);
         if constexpr (ROWWAVE) {                            // this wave's partial is final: one (row, head, chunk) per wave
             if (row_ok) {
                 float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
@@ -222,19 +263,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             }
             return;
         }
-        if (lane == 0) { qm[w] = M; ql[w] = L; }
-        qo[w][lane] = O;
+        if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
+        S.qo[w][lane] = O;
     }
     __syncthreads();
     if (w == 0) {
-        const float M = fmaxf(fmaxf(qm[0], qm[1]), fmaxf(qm[2], qm[3]));
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float f = expf(qm[i] - M);
-            L = fmaf(ql[i], f, L);
-            O = fmaf(qo[i][lane], f, O);
-        }
+        float M, L, O;
+        attn_fold_block<KT>(S, lane, M, L, O);
         float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
         float* op = ws + (size_t)H * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
         if (lane == 0) { ml[0] = M; ml[1] = L; }

@@ -64,6 +64,14 @@ __device__ inline float wave_sum(float v) {
     v = row_sum16(v);
     return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
+// max over each aligned group of 16 lanes (a DPP row); every lane of the row gets it
+__device__ inline float row_max16(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
 __device__ inline float wave_max(float v) {
     v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
     v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
@@ -82,11 +90,29 @@ __device__ inline float group_sum(float v) {
     return v;
 }
 
-// LayerNorm of one row held by a 256-thread block (thread t owns the float4 chunks t, t + 256, ... of the row; chunks
-// >= nq are padding), ONE barrier: both moments are accumulated on the shifted data d = x - x0 (x0 = element 0 of the row,
-// the same value in every thread), so var = E[d^2] - E[d]^2 loses nothing to cancellation however large the row's mean is.
-// In place: xv <- (x - mean) * rstd * g + b.  `red` = 8 floats of LDS.  Used by the GEMV prologue (gemv.hpp) and the
-// batched rows prologue (gemm_decode.hpp): a batched row sees exactly the bits of its batch-1 run.
+// ---- LayerNorm of one row, one barrier -------------------------------------------------------------------------------------
+// Both moments are accumulated on the shifted data d = x - x0 (x0 = element 0 of the row, the same value in every thread), so
+// var = E[d^2] - E[d]^2 loses nothing to cancellation however large the row's mean is.  The three pieces below are shared by
+// the block-level prologues (gemv.hpp, gemm_decode.hpp) and the persistent decode kernel (persist.hpp), written with explicit
+// fmaf so that every path produces the same bits: chunk moments -> per-wave sums (wave_sum) -> (red[0]+red[1])+(red[2]+red[3]).
+__device__ __forceinline__ void ln_chunk_moments(f32x4& x, float x0, float& s, float& q) {      // x <- x - x0; adds the chunk's sums
+    x.x -= x0; x.y -= x0; x.z -= x0; x.w -= x0;
+    s += (x.x + x.y) + (x.z + x.w);
+    q += fmaf(x.x, x.x, x.y * x.y) + fmaf(x.z, x.z, x.w * x.w);
+}
+__device__ __forceinline__ void ln_finish(float s0, float s1, float s2, float s3, float q0, float q1, float q2, float q3, int K, float eps,
+                                          float& md, float& rstd) {
+    md = ((s0 + s1) + (s2 + s3)) / (float)K;                                                  // mean of the shifted row
+    const float var = fmaxf(fmaf(-md, md, ((q0 + q1) + (q2 + q3)) / (float)K), 0.f);
+    rstd = 1.0f / sqrtf(var + eps);
+}
+__device__ __forceinline__ float ln_apply1(float d, float md, float rstd, float g, float b) { return fmaf((d - md) * rstd, g, b); }
+__device__ __forceinline__ void ln_apply(f32x4& x, float md, float rstd, const f32x4& g, const f32x4& b) {   // x holds d = x - x0
+    x.x = ln_apply1(x.x, md, rstd, g.x, b.x); x.y = ln_apply1(x.y, md, rstd, g.y, b.y);
+    x.z = ln_apply1(x.z, md, rstd, g.z, b.z); x.w = ln_apply1(x.w, md, rstd, g.w, b.w);
+}
+// block form: thread t owns the float4 chunks t, t + 256, ... of the row (chunks >= nq are padding).  In place:
+// xv <- (x - mean) * rstd * g + b.  `red` = 8 floats of LDS.
 template <int NCH>
 __device__ inline void ln_block_onepass(f32x4 (&xv)[NCH], const f32x4 (&gv)[NCH], const f32x4 (&bv)[NCH], float x0, int tid, int nq, int K,
                                         float eps, float* red) {
@@ -94,26 +120,16 @@ __device__ inline void ln_block_onepass(f32x4 (&xv)[NCH], const f32x4 (&gv)[NCH]
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        xv[j].x -= x0; xv[j].y -= x0; xv[j].z -= x0; xv[j].w -= x0;
-        if (tid + 256 * j < nq) {
-            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
-            q += (xv[j].x * xv[j].x + xv[j].y * xv[j].y) + (xv[j].z * xv[j].z + xv[j].w * xv[j].w);
-        }
+        if (tid + 256 * j < nq) ln_chunk_moments(xv[j], x0, s, q);
     }
     s = wave_sum(s);
     q = wave_sum(q);
     if (lane == 0) { red[w] = s; red[4 + w] = q; }
     __syncthreads();
-    const float md = ((red[0] + red[1]) + (red[2] + red[3])) / (float)K;                    // mean of the shifted row
-    const float var = fmaxf(((red[4] + red[5]) + (red[6] + red[7])) / (float)K - md * md, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
+    float md, rstd;
+    ln_finish(red[0], red[1], red[2], red[3], red[4], red[5], red[6], red[7], K, eps, md, rstd);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        xv[j].x = (xv[j].x - md) * rstd * gv[j].x + bv[j].x;
-        xv[j].y = (xv[j].y - md) * rstd * gv[j].y + bv[j].y;
-        xv[j].z = (xv[j].z - md) * rstd * gv[j].z + bv[j].z;
-        xv[j].w = (xv[j].w - md) * rstd * gv[j].w + bv[j].w;
-    }
+    for (int j = 0; j < NCH; ++j) ln_apply(xv[j], md, rstd, gv[j], bv[j]);
 }
 
 // exact (erf) GELU, as torch.nn.GELU() / HF "gelu"

@@ -26,6 +26,7 @@
 #include "gemm_decode.hpp"
 #include "gemv.hpp"
 #include "misc.hpp"
+#include "persist.hpp"
 #include "state.hpp"
 #include "weights.hpp"
 
@@ -49,11 +50,6 @@ struct MaError : std::exception {
     } while (0)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-
-struct DecLayerPtrs {
-    const void *qkv_w, *o_w, *fc1_w, *fc2_w;
-    const float *qkv_b, *o_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-};
 
 }  // namespace
 
@@ -102,6 +98,15 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
+    // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
+    int opt_decode_impl = 0;         // 0: chain of launches; 1: one persistent launch per step (when eligible)
+    int n_cus = 0;
+    bool persist_shape = false;      // shape / device eligibility (fixed at creation)
+    bool embtab_ready = false;
+    DecLayerPtrs* d_layers = nullptr;
+    u64* d_gran = nullptr; unsigned* d_serial = nullptr; unsigned* d_err = nullptr; unsigned* h_err = nullptr;
+    float* d_embtab = nullptr;       // [codebook_size][hidden] fp32: input_layer(codebook row) + bias, built by the chain's own GEMV
+    u64* d_ptrace = nullptr;
     bf16_t *d_xb = nullptr, *d_ffb = nullptr;      // bf16 activations of the batched path: [max_batch][hidden], [max_batch][ffn]
     float *d_ks_o = nullptr, *d_ks_f = nullptr;    // split-K partials of out_proj / fc2: [4][max_batch][hidden]
 
@@ -422,9 +427,61 @@ void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm, Rows rw) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- persistent decode step (persist.hpp) ----------------------------------------------------------------------------------
+// eligible: bf16 policy, one row, greedy, the 350M layer shape, a device with exactly the 256 CUs the kernel assigns roles to
+bool persist_eligible(ma_engine* e, int B, int do_sample) { return e->persist_shape && B == 1 && !do_sample; }
+bool persist_selected(ma_engine* e, int B, int do_sample) { return e->opt_decode_impl == 1 && persist_eligible(e, B, do_sample); }
+
+// embedding table of the persistent step: row v = input_layer(codebook[v]) + bias, computed by the launch chain's own GEMV
+// (same kernel, same rounding points: the table holds exactly the bits the chain's embedding launch produces for token v + 3)
+void ensure_embtab(ma_engine* e, hipStream_t s) {
+    if (e->embtab_ready) return;
+    const ma_config& c = e->cfg;
+    const float* cb = e->PF(DEC + "quantize_codebooks");
+    for (int v = 0; v < c.codebook_size; ++v) {
+        GemvArgs a{};
+        a.round_x = 1; a.act = ACT_NONE; a.epi = EPI_PLAIN;
+        a.W = e->P(DEC + "input_layer.weight"); a.bias = e->PF(DEC + "input_layer.bias"); a.x = cb + (size_t)v * c.codebook_dim;
+        a.y = e->d_embtab + (size_t)v * c.hidden; a.N = c.hidden; a.K = c.codebook_dim;
+        hipError_t r = launch_gemv<bf16_t>(a, s, 1);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("embedding table gemv failed: ") + hipGetErrorString(r));
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+    e->embtab_ready = true;
+}
+
+void enqueue_persist_step(ma_engine* e, hipStream_t s, StepTimer& tm, u64* trace = nullptr) {
+    if (!tm.on(2)) return;
+    const ma_config& c = e->cfg;
+    PersistArgs a{};
+    a.layers = e->d_layers; a.L = c.layers;
+    a.lm_head = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); a.V = e->V;
+    a.embtab = e->d_embtab; a.extra = e->PF(DEC + "extra_embeds.weight"); a.tokpos = e->PF(DEC + "token_embed_positions.weight");
+    a.cond = e->PF(DEC + "cond_embed.weight"); a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
+    a.kv = reinterpret_cast<bf16_t*>(e->kv); a.kv_plane = e->kv_plane / e->kv_elem; a.max_seq = e->maxseq;
+    a.st = e->d_st; a.tokens_out = e->w_tokens; a.logits = e->d_logits;
+    a.gran = e->d_gran; a.serial = e->d_serial; a.err = e->d_err; a.trace = trace;
+    hipError_t r = launch_persist_decode(a, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("persistent decode launch failed: ") + hipGetErrorString(r));
+}
+
+// the persistent step reports a bounded wait that expired through a device word: turn it into an error (and clear it)
+void check_persist_error(ma_engine* e, hipStream_t s) {
+    if (!e->persist_shape) return;
+    HIP_CHECK(hipMemcpyAsync(e->h_err, e->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (*e->h_err) {
+        const unsigned code = *e->h_err;
+        HIP_CHECK(hipMemsetAsync(e->d_err, 0, sizeof(unsigned), s));
+        throw MaError(MA_ERR_HIP, "persistent decode step: a bounded wait expired (code " + std::to_string(code) +
+                                  ": 1 loader, 2 comm, 4 compute, 8 gather) -- the 256 workgroups were not all resident, or a hand-off was lost");
+    }
+}
+
 // One full decode step (shape_opt.py:318-328 embedding branch -> 24 layers -> lm_head -> pick) for rows r0..r0+B-1.
 // Replayable: no host-side step-dependent argument.
-void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTimer& tm, Rows rw = Rows{}) {
+void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTimer& tm, Rows rw = Rows{}, int impl = 0) {
+    if (impl == 1) { enqueue_persist_step(e, s, tm); return; }
     const ma_config& c = e->cfg;
     const int H = c.hidden;
     float* de = e->d_e + (size_t)rw.r0 * H;
@@ -456,16 +513,17 @@ void drop_graphs(ma_engine* e) {
     e->gexec.clear(); e->graph.clear();
 }
 
-// one captured step per batch size (the grids depend on B)
-void ensure_graph(ma_engine* e, int B) {
-    if (!e->cfg.use_graph || e->gexec.count(B)) return;
+// one captured step per batch size (the grids depend on B) and step implementation (key = B + 1000 * impl)
+void ensure_graph(ma_engine* e, int B, int impl = 0) {
+    const int key = B + 1000 * impl;
+    if (!e->cfg.use_graph || e->gexec.count(key)) return;
     StepTimer none;
     if (!e->cap_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     hipStream_t s = e->cap_stream;
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-        enqueue_decode_step(e, s, -1, none, Rows{0, B});
+        enqueue_decode_step(e, s, -1, none, Rows{0, B}, impl);
     } catch (...) {
         (void)hipStreamEndCapture(s, &g);
         if (g) (void)hipGraphDestroy(g);
@@ -475,12 +533,12 @@ void ensure_graph(ma_engine* e, int B) {
     hipGraphExec_t ge = nullptr;
     hipError_t r = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     if (r != hipSuccess) { (void)hipGraphDestroy(g); HIP_CHECK(r); }
-    e->graph[B] = g; e->gexec[B] = ge;
+    e->graph[key] = g; e->gexec[key] = ge;
 }
 
-void launch_step(ma_engine* e, hipStream_t s, int B) {
-    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s));
-    else { StepTimer none; enqueue_decode_step(e, s, -1, none, Rows{0, B}); }
+void launch_step(ma_engine* e, hipStream_t s, int B, int impl = 0) {
+    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec.at(B + 1000 * impl), s));
+    else { StepTimer none; enqueue_decode_step(e, s, -1, none, Rows{0, B}, impl); }
 }
 
 // prefill of rows row0 .. row0+B-1 in ONE pass (the samples are stacked along the GEMM rows: M = B * T): ShapeOPTDecoder.forward
@@ -570,7 +628,9 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
     const int total = B * e->maxnew;
     hipLaunchKernelGGL(fill_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, e->w_tokens, (long long)TOK_PAD, total);
     HIP_CHECK(hipGetLastError());
-    ensure_graph(e, B);
+    const int impl = persist_selected(e, B, sc.do_sample) ? 1 : 0;
+    if (impl == 1) ensure_embtab(e, s);
+    ensure_graph(e, B, impl);
     init_state(e, s, sc, B, maxn);
     // prefill in groups of rows (bounded workspace: prefill_rows samples at a time)
     for (int b0 = 0; b0 < B; b0 += e->prefill_rows) {
@@ -584,10 +644,11 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
     bool finished = false;
     while (produced < maxn && !finished) {
         const int burst = std::min(sc.check_every, maxn - produced);
-        for (int i = 0; i < burst; ++i) launch_step(e, s, B);
+        for (int i = 0; i < burst; ++i) launch_step(e, s, B, impl);
         produced += burst;
         HIP_CHECK(hipMemcpyAsync(e->h_state, e->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        if (impl == 1) check_persist_error(e, s);
         finished = true;
         for (int b = 0; b < B; ++b) finished = finished && e->h_state[b].finished != 0;
     }
@@ -691,6 +752,25 @@ void build_engine(ma_engine* e) {
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
     HIP_CHECK(hipMemset(e->d_st, 0, MB * sizeof(DecState)));
+    {   // persistent decode step: shape / device eligibility and its buffers
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, e->device));
+        e->n_cus = prop.multiProcessorCount;
+        e->persist_shape = e->bf16 && c.hidden == PS_H && c.ffn == PS_F && c.heads == PS_HEADS && c.codebook_dim == PS_H && c.heads * ATTN_NCHUNK == PS_CUS &&
+                           e->V >= PS_CUS * 32 && e->V <= PS_CUS * 33 && e->n_cus == PS_CUS && (size_t)prop.sharedMemPerBlockOptin >= PL_TOTAL;
+        if (e->persist_shape && persist_prepare() != hipSuccess) { (void)hipGetLastError(); e->persist_shape = false; }
+        if (e->persist_shape) {
+            e->d_layers = e->dmalloc<DecLayerPtrs>(c.layers);
+            e->d_gran = e->dmalloc<u64>(PG_TOTAL); e->d_serial = e->dmalloc<unsigned>(1); e->d_err = e->dmalloc<unsigned>(1);
+            e->d_embtab = e->dmalloc<float>((size_t)c.codebook_size * H);
+            e->d_ptrace = e->dmalloc<u64>((size_t)PS_CUS * (PS_TRACE_EVENTS + PS_TRACE2_EVENTS));
+            HIP_CHECK(hipMemset(e->d_gran, 0, PG_TOTAL * sizeof(u64)));
+            const unsigned one = 1u;
+            HIP_CHECK(hipMemcpy(e->d_serial, &one, sizeof(unsigned), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemset(e->d_err, 0, sizeof(unsigned)));
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), sizeof(unsigned)));
+        }
+    }
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));
     // dense workspace, one sample
@@ -727,6 +807,7 @@ void build_engine(ma_engine* e) {
         w.ln1_g = e->PF(p + "self_attn_layer_norm.weight"); w.ln1_b = e->PF(p + "self_attn_layer_norm.bias");
         w.ln2_g = e->PF(p + "final_layer_norm.weight"); w.ln2_b = e->PF(p + "final_layer_norm.bias");
     }
+    if (e->persist_shape) HIP_CHECK(hipMemcpy(e->d_layers, e->dl.data(), c.layers * sizeof(DecLayerPtrs), hipMemcpyHostToDevice));
 }
 
 template <typename F>
@@ -784,6 +865,7 @@ void ma_engine_destroy(ma_engine* e) {
     if (e->arena) (void)hipFree(e->arena);
     if (e->kv) (void)hipFree(e->kv);
     if (e->h_state) (void)hipHostFree(e->h_state);
+    if (e->h_err) (void)hipHostFree(e->h_err);
     if (e->h_tokens) (void)hipHostFree(e->h_tokens);
     delete e;
 }
@@ -797,6 +879,10 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
+        else if (n == "decode_impl") {
+            if (value != 0 && value != 1) throw MaError(MA_ERR_INVALID, "decode_impl must be 0 (launch chain) or 1 (persistent step)");
+            e->opt_decode_impl = (int)value;
+        }
         else if (n == "gemv_rpw") {
             if (value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_rpw must be 1, 2 or 4");
             gemv_rpw_big() = (int)value;
@@ -824,7 +910,7 @@ int ma_engine_finalize_weights(ma_engine* e) {
     return guarded(e, [&] {
         std::string missing;
         if (!pack_complete(e->L, e->ps, missing)) throw MaError(MA_ERR_MISSING, "checkpoint incomplete, missing: " + missing);
-        e->weights_ready = true;
+        e->weights_ready = true; e->embtab_ready = false;
     });
 }
 
@@ -836,7 +922,7 @@ int ma_engine_arena(ma_engine* e, void** dev_ptr, size_t* bytes) {
 
 int ma_engine_mark_weights_loaded(ma_engine* e) {
     if (!e) return MA_ERR_INVALID;
-    e->weights_ready = true;
+    e->weights_ready = true; e->embtab_ready = false;
     return MA_OK;
 }
 
@@ -855,7 +941,7 @@ int ma_engine_broadcast_weights(ma_engine* e, void* nccl_comm, int root, void* s
         }
         const int rc = fn(e->arena, e->arena, e->L.bytes, /*ncclInt8*/ 0, root, nccl_comm, reinterpret_cast<hipStream_t>(stream));
         if (rc != 0) throw MaError(MA_ERR_NCCL, "ncclBroadcast failed with code " + std::to_string(rc));
-        e->weights_ready = true;
+        e->weights_ready = true; e->embtab_ready = false;
     });
 }
 
@@ -920,7 +1006,7 @@ int ma_engine_upload_arena(ma_engine* e, const void* host_arena, size_t bytes) {
     return guarded(e, [&] {
         if (bytes != e->L.bytes) throw MaError(MA_ERR_SHAPE, "arena size mismatch");
         HIP_CHECK(hipMemcpy(e->arena, host_arena, bytes, hipMemcpyHostToDevice));
-        e->weights_ready = true;
+        e->weights_ready = true; e->embtab_ready = false;
     });
 }
 
@@ -1110,7 +1196,10 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
         sc.suppress_eos = 1;
         const int B = std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch));
-        ensure_graph(e, B);
+        const int impl = persist_selected(e, B, 0) ? 1 : 0;
+        if (impl == 1) ensure_embtab(e, s);
+        ensure_graph(e, B, impl);
+        const int gkey = B + 1000 * impl;
         auto reset = [&] {
             init_state(e, s, sc, B, e->maxnew);
             // state as if t tokens had been generated and the cache held kv_len-1 rows
@@ -1126,13 +1215,13 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         auto timed = [&](int only_cls, int* launches) -> float {
             StepTimer tm; tm.only_cls = only_cls;
             reset();
-            if (only_cls == -2) { HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s)); }                // warm
-            else { StepTimer w; w.only_cls = only_cls; enqueue_decode_step(e, s, -1, w, Rows{0, B}); }
+            if (only_cls == -2) { HIP_CHECK(hipGraphLaunch(e->gexec.at(gkey), s)); }             // warm
+            else { StepTimer w; w.only_cls = only_cls; enqueue_decode_step(e, s, -1, w, Rows{0, B}, impl); }
             reset();
             HIP_CHECK(hipEventRecord(a, s));
             for (int i = 0; i < steps; ++i) {
-                if (only_cls == -2) HIP_CHECK(hipGraphLaunch(e->gexec.at(B), s));
-                else enqueue_decode_step(e, s, -1, tm, Rows{0, B});
+                if (only_cls == -2) HIP_CHECK(hipGraphLaunch(e->gexec.at(gkey), s));
+                else enqueue_decode_step(e, s, -1, tm, Rows{0, B}, impl);
             }
             HIP_CHECK(hipEventRecord(b, s));
             HIP_CHECK(hipStreamSynchronize(s));
@@ -1143,11 +1232,13 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         };
         out->step_ms_eager = timed(-1, nullptr) / steps;
         if (e->cfg.use_graph) out->step_ms_graph = timed(-2, nullptr) / steps;
-        for (int cls : {0, 1, 3}) {
+        for (int cls : {0, 1, 2, 3}) {
+            if ((impl == 1) != (cls == 2)) continue;          // the persistent step is one launch of its own class
             int n = 0;
             out->ms[cls] = timed(cls, &n);
             out->launches[cls] = n;
         }
+        if (impl == 1) check_persist_error(e, s);
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     });
 }
@@ -1182,5 +1273,45 @@ int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launch
         HIP_CHECK(hipFree(d_tr));
     });
 }
+
+// In-kernel timeline of ONE persistent decode step (diagnostics): for every workgroup, the 100 MHz real-time counter at kernel
+// start, then two stamps per edge (local share published = start of the sweep | gather complete), then the end.
+int ma_persist_trace(ma_engine* e, int kv_len, uint64_t* host_out, int32_t* n_events, void* stream) {
+    if (!e || !host_out || !n_events) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        require_ready(e);
+        if (!e->persist_shape) throw MaError(MA_ERR_STATE, "the persistent decode step is not available for this configuration / device");
+        if (kv_len < e->T + 1 || kv_len + 16 > e->maxseq) throw MaError(MA_ERR_INVALID, "kv_len out of range");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
+        sc.suppress_eos = 1;
+        ensure_embtab(e, s);
+        init_state(e, s, sc, 1, e->maxnew);
+        hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5, 1);
+        HIP_CHECK(hipGetLastError());
+        StepTimer none;
+        for (int i = 0; i < 3; ++i) enqueue_persist_step(e, s, none);
+        const size_t tr_words = (size_t)PS_CUS * (PS_TRACE_EVENTS + PS_TRACE2_EVENTS);
+        HIP_CHECK(hipMemsetAsync(e->d_ptrace, 0, tr_words * sizeof(u64), s));
+        enqueue_persist_step(e, s, none, e->d_ptrace);
+        HIP_CHECK(hipMemcpyAsync(host_out, e->d_ptrace, tr_words * sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        check_persist_error(e, s);
+        *n_events = 2 * (6 * e->cfg.layers + 1) + 2;
+    });
+}
+
+// the last decode step's logits of batch row `row` (V floats, device -> caller's device buffer): parity tests compare the two
+// step implementations bit for bit
+int ma_engine_read_logits(ma_engine* e, int row, float* out, void* stream) {
+    if (!e || !out) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        if (row < 0 || row >= e->cfg.max_batch) throw MaError(MA_ERR_INVALID, "row out of range");
+        HIP_CHECK(hipMemcpyAsync(out, e->d_logits + (size_t)row * e->V, (size_t)e->V * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+    });
+}
+
+// 1 when the persistent decode step can run on this engine (bf16, 350M layer shape, 256-CU device), else 0
+int ma_engine_persist_available(ma_engine* e) { return e && e->persist_shape ? 1 : 0; }
 
 }  // extern "C"

@@ -236,11 +236,30 @@ class Engine:
         return {"coords": coords, "tokens": tokens[:, :ngen.value], "lengths": np.array(list(lengths), dtype=np.int32),
                 "ids": ids, "latents": latents}
 
+    # ---------------------------------------------------------------- persistent decode step (csrc/persist.hpp)
+    def persist_available(self) -> bool:
+        """True when `set_option("decode_impl", 1)` can take effect: bf16, 350M layer shape, 256-CU device."""
+        return bool(self.lib.ma_engine_persist_available(self.h))
+
+    def read_logits(self, row: int = 0) -> torch.Tensor:
+        """Logits (codebook_size + 3) of the most recent decode step of batch row `row`."""
+        out = torch.empty(self.cfg.vocab, dtype=torch.float32, device=self.device)
+        self._check(self.lib.ma_engine_read_logits(self.h, row, _ptr(out), _stream_ptr()))
+        return out
+
+    def persist_trace(self, kv_len: int) -> np.ndarray:
+        """(256 workgroups, n_events) 100 MHz ticks of one persistent step: start, per edge {sweep start, gather done}, end."""
+        out = np.zeros(256 * (320 + 512), dtype=np.uint64)
+        n = C.c_int32()
+        self._check(self.lib.ma_persist_trace(self.h, kv_len, C.c_void_p(out.ctypes.data), C.byref(n), _stream_ptr()))
+        self.last_compute_trace = out[256 * 320:].reshape(256, 512)
+        return out[:256 * 320].reshape(256, 320)[:, :n.value]
+
     # ---------------------------------------------------------------- measurement
     def profile_decode(self, kv_len: int, steps: int = 4) -> Dict[str, object]:
         kt = _lib.KernelTiming()
         self._check(self.lib.ma_profile_decode(self.h, kv_len, steps, C.byref(kt), _stream_ptr()))
-        names = ["gemv", "attn_decode", "unused", "pick"]
+        names = ["gemv", "attn_decode", "persist", "pick"]
         return {"launches": {n: kt.launches[i] for i, n in enumerate(names)}, "ms": {n: kt.ms[i] for i, n in enumerate(names)},
                 "step_ms_graph": kt.step_ms_graph, "step_ms_eager": kt.step_ms_eager, "steps": steps, "kv_len": kv_len}
 

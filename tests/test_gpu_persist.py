@@ -1,0 +1,123 @@
+"""The persistent decode step (csrc/persist.hpp: one resident launch per step) against the launch chain it replaces, at the
+BASELINE.json configs[1] shape (350M, bf16, batch 1, greedy): the two implementations run the same arithmetic in the same
+order, so the test demands bit-identical logits and token-identical streams, not a tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from meshanything_amd.config import MAConfig, DTYPE_BF16
+from conftest import cached_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(golden_dir):
+    from meshanything_amd.engine import Engine
+    cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=2)
+    e = Engine(cfg)
+    e.load_weights(cached_state_dict(cfg).items())
+    if not e.persist_available():
+        pytest.skip("persistent decode step not available on this device (needs 256 CUs)")
+    d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
+    x = torch.from_numpy(d["mouse_norm"])[None]
+    _, prefix = e.encode(x.cuda())
+    e.prefix = prefix
+    return e
+
+
+def _gen(eng, impl, **kw):
+    eng.set_option("decode_impl", impl)
+    try:
+        toks, lengths = eng.generate(eng.prefix, **kw)
+        logits = eng.read_logits(0).clone()
+    finally:
+        eng.set_option("decode_impl", 0)
+    torch.cuda.synchronize()
+    return toks.cpu(), lengths, logits.cpu()
+
+
+def test_persistent_step_is_bitwise_the_launch_chain(eng):
+    for n in (2, 3, 17, 64):                        # the last step's logits after n - 1 decode steps
+        t0, l0, g0 = _gen(eng, 0, max_new_tokens=n, suppress_eos=True)
+        t1, l1, g1 = _gen(eng, 1, max_new_tokens=n, suppress_eos=True)
+        assert torch.equal(t0, t1), f"tokens differ within {n} steps: {t0.tolist()} vs {t1.tolist()}"
+        same = torch.equal(g0.view(torch.int32), g1.view(torch.int32))
+        assert same, f"logits of step {n - 1} differ: max abs {float((g0 - g1).abs().max()):.3e} at {int((g0 - g1).abs().argmax())}"
+
+
+def test_persistent_generate_400_tokens_token_identical(eng):
+    n = int(os.environ.get("MA_TEST_GEN_TOKENS", "400"))
+    t0, l0, _ = _gen(eng, 0, max_new_tokens=n, suppress_eos=True)
+    t1, l1, _ = _gen(eng, 1, max_new_tokens=n, suppress_eos=True)
+    assert t0.shape == (1, n) and torch.equal(t0, t1)
+    again, _, _ = _gen(eng, 1, max_new_tokens=n, suppress_eos=True)
+    assert torch.equal(t1, again), "the persistent step is not deterministic"
+    # eos allowed: same stopping point, same eos / pad tail
+    t0, l0, _ = _gen(eng, 0, max_new_tokens=200, check_every=7)
+    t1, l1, _ = _gen(eng, 1, max_new_tokens=200, check_every=7)
+    assert torch.equal(t0, t1) and list(l0) == list(l1)
+    # graph replay == eager launches
+    eng.set_option("use_graph", 0)
+    try:
+        e1, _, _ = _gen(eng, 1, max_new_tokens=64, suppress_eos=True)
+    finally:
+        eng.set_option("use_graph", 1)
+    g1, _, _ = _gen(eng, 1, max_new_tokens=64, suppress_eos=True)
+    assert torch.equal(e1, g1)
+
+
+def test_persistent_falls_back_outside_its_envelope(eng):
+    """Sampling and batches of more than one row keep using the launch chain (same results as with decode_impl 0)."""
+    u = torch.rand(1, 48, generator=torch.Generator().manual_seed(5))
+    eng.set_option("decode_impl", 1)
+    try:
+        a, _ = eng.generate(eng.prefix, sampling=True, uniforms=u, max_new_tokens=48, suppress_eos=True)
+        two = torch.cat([eng.prefix, eng.prefix])
+        b, _ = eng.generate(two, max_new_tokens=48, suppress_eos=True)
+    finally:
+        eng.set_option("decode_impl", 0)
+    a0, _ = eng.generate(eng.prefix, sampling=True, uniforms=u, max_new_tokens=48, suppress_eos=True)
+    b0, _ = eng.generate(torch.cat([eng.prefix, eng.prefix]), max_new_tokens=48, suppress_eos=True)
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+
+
+def test_persistent_step_timing_report(eng):
+    """Report-only: decode step (graph replay) of both implementations at three cache lengths + the edge timeline."""
+    cfg = eng.cfg
+    for L in (300, 3858, cfg.max_seq - 80):
+        row = {}
+        for impl in (0, 1):
+            eng.set_option("decode_impl", impl)
+            eng.profile_decode(L, 2)
+            p = eng.profile_decode(L, 16)
+            row[impl] = p["step_ms_graph"] * 1e3
+        eng.set_option("decode_impl", 0)
+        print(f"[persist A/B] kv_len {L:5d}: launch chain {row[0]:7.1f} us/step | persistent {row[1]:7.1f} us/step | ratio {row[1] / row[0]:.3f}")
+    tr = eng.persist_trace(3858).astype(np.int64)
+    t = (tr - tr[:, :1]) / 100.0                       # us since each workgroup's start
+    ev = t[:, 1:-1].reshape(256, -1, 2)                # per edge: (sweep start, gather done)
+    wait = ev[:, :, 1] - ev[:, :, 0]
+    seq = ["qkv", "part", "a", "y1", "ffn"] + ["y2", "qkv", "part", "a", "y1", "ffn"] * (cfg.layers - 1) + ["y2", "arg"]
+    assert len(seq) == wait.shape[1]
+    agg = {}
+    for i, k in enumerate(seq):
+        agg.setdefault(k, []).append(np.median(wait[:, i]))
+    print("[persist trace] median sweep time per edge kind (us, median over workgroups then mean over layers): " +
+          ", ".join(f"{k} {np.mean(v):.2f}" for k, v in agg.items()))
+    # compute wave 0 of every workgroup: 19 stamps per layer
+    ct = eng.last_compute_trace.astype(np.int64)
+    nl = cfg.layers
+    ct = ct[:, :19 * nl].reshape(256, nl, 19) / 100.0
+    labels = ["qkv:in+LN", "qkv:weights", "qkv:dots", "qkv:publish", "attn:partial out", "part gathered", "merged out",
+              "oproj:in", "oproj:weights", "oproj:dots", "oproj:publish", "fc1:in+LN", "fc1:weights", "fc1:dots", "fc1:publish",
+              "fc2:in", "fc2:weights", "fc2:dots", "fc2:publish"]
+    d = np.diff(ct, axis=2)                              # (256, nl, 18) intervals inside a layer
+    first = ct[:, 1:, 0] - ct[:, :-1, 18]                # y2 edge + LN of the next layer
+    med = np.median(d[:, 1:, :], axis=(0, 1))
+    print("[persist compute-wave timeline] median interval (us) ending at each point, layers 1..: y2 edge+LN %.2f | " % np.median(first) +
+          " | ".join(f"{labels[i + 1]} {med[i]:.2f}" for i in range(18)))
+    print(f"[persist compute-wave timeline] layer period {np.median(ct[:, 2:, 0] - ct[:, 1:-1, 0]):.2f} us")
+    print(f"[persist trace] step span: {np.median(t[:, -1]):.1f} us (median workgroup), in sweeps {np.median(wait.sum(axis=1)):.1f} us")
