@@ -98,7 +98,8 @@ def main():
     ap.add_argument("--faces", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=1, help="shapes per GPU decoded together (BASELINE.json configs 3-5 use 64 / 8)")
+    ap.add_argument("--batch", type=int, default=0, help="shapes per GPU decoded together; default: 1 at --gpus 1 (BASELINE.json configs[1]), "
+                                                         "8 at --gpus N > 1 (the metric's 'batch=8xN shapes'); configs 3 / 5 use 64 / 8")
     ap.add_argument("--sampling", action="store_true", help="top-k 50 / top-p 0.95 sampling (configs 3-4) instead of greedy")
     ap.add_argument("--no-batched-table", action="store_true", help="skip the batch 8 / 64 decode-step table of the default run")
     args = ap.parse_args()
@@ -107,8 +108,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.batch <= 0:
+        args.batch = 1 if args.gpus == 1 else 8             # BASELINE.json metric: batch 1, and batch 8 x N shapes
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL path runs even with one rank
@@ -122,6 +124,7 @@ def main():
         real_stdout = os.dup(1)
         os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from meshanything_amd.engine import Engine
     from meshanything_amd import dp
@@ -243,8 +246,10 @@ def main():
             "metric": f"face-tokens/sec ({args.faces}-face cap, batch {args.batch} per GPU) + sec/mesh", "value": round(total_tokens / dt, 2), "unit": "face-tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[{1 if args.batch == 1 else (2 if args.faces == 800 else 4)}]"
-                                    + (" (per-GPU share of configs[3] when launched on 8 GPUs)" if args.batch > 1 and args.faces == 800 else "") + ": "
+            "config": {"workload": ((f"BASELINE.json metric 'batch=8xN shapes' ({world * args.batch} shapes over {world} GPUs, the layout of configs[3] at 8 per GPU)"
+                                     if world > 1 and args.batch == 8 else
+                                     f"BASELINE.json configs[{1 if args.batch == 1 else (2 if args.faces == 800 else 4)}]"
+                                     + (" (per-GPU share of configs[3] when launched on 8 GPUs)" if args.batch > 1 and args.faces == 800 else "")) + ": "
                                     + ("single shape pc_examples/mouse.npy (Dataset-normalised, seed 0)" if args.batch == 1
                                        else f"batch {args.batch} per GPU (mouse.npy + seeded synthetic 4096-pt clouds)")
                                     + f", 350M shape, {args.dtype}, 1xMI355X per rank, {'top-k 50 / top-p 0.95 sampling' if args.sampling else 'greedy'}, "

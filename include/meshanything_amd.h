@@ -218,6 +218,22 @@ MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_tim
 MA_API int  ma_trace_decode(ma_engine *e, int kv_len, uint64_t *host_out, int max_launches, int max_blocks, int32_t *kinds,
                             int32_t *blocks, int32_t *n_launches, void *stream);
 
+/* ---- batched decode step kernels (csrc/gemm_decode.hpp; replace the same nn.Linear calls as ma_op_gemv when B rows step
+ * together, meshanything.py:143-162 with batch > 1).  All pointers device.
+ * ma_op_gemm_dec: Y[B,N] = act(Xb[B,K] . W[N,K]^T + bias) + res on the bf16 matrix cores; W, Xb bf16; y fp32 and / or yb bf16
+ *   output; ksplit > 1: y receives the raw partial sums [ksplit][B][N] (bias / res / act must be null / none).
+ * ma_op_gemm_dec_qkv: the fused q/k/v projection epilogue: rows [0,H) -> q (B,H) fp32, [H,2H) / [2H,3H) -> K / V cache
+ *   ([B] planes kv_row_stride elements apart, each (H/64, max_seq, 64) bf16) at position `pos`.
+ * ma_op_rows_prologue: per-row prologue (pro 0 plain | 1 LayerNorm | 2 merge of the split-KV attention partials): sums
+ *   `nparts` partial buffers [nparts][B][K] + bias + res, normalises, writes fp32 (xn_out, may be NULL) and bf16 (xb_out). */
+MA_API int  ma_op_gemm_dec(const void *W, const float *bias, const void *xb, const float *res, float *y, void *yb, int N, int K,
+                           int B, int act, int ksplit, void *stream);
+MA_API int  ma_op_gemm_dec_qkv(const void *W, const float *bias, const void *xb, float *q, void *kcache, void *vcache, int H,
+                               int max_seq, int pos, int B, size_t kv_row_stride, void *stream);
+MA_API int  ma_op_rows_prologue(int pro, const float *x, int nparts, int B, const float *bias, const float *res, const float *ln_g,
+                                const float *ln_b, float ln_eps, const float *attn_ws, int attn_heads, float *xn_out,
+                                void *xb_out, int K, void *stream);
+
 /* ---- persistent decode step (csrc/persist.hpp): the whole batch-1 greedy step as ONE resident launch instead of the
  * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()
  * and the call is batch 1 / greedy, otherwise the chain runs.  replaces: the same reference calls as ma_generate's steps

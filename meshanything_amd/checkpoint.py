@@ -190,13 +190,31 @@ _KIND_INIT = {
 }
 
 
+# init="hf": what the reference's own constructors would leave before training: transformers' `_init_weights`
+# for the OPT decoder / BERT detokenizer / top-level projections (Linear and Embedding N(0, 0.02), biases 0, LayerNorm (1, 0)),
+# Michelangelo's `init_linear` (std 0.25 / sqrt(width), transformer_blocks.py:12-15) for the point encoder, codebook N(0, 1)
+# (meshanything.py:118 loads a trained codebook; unit variance is its scale).  Logit margins are ~5x smaller than under the
+# default init: used by the report-only fidelity tests, not by parity gates.
+def _hf_init(cfg: MAConfig, name: str, kind: str):
+    miche = name.startswith(PE)
+    if kind in ("w", "w_attn", "w_half", "w_head"):
+        return ("normal", 0.25 / float(np.sqrt(cfg.enc_width)) if miche else 0.02)
+    if kind == "bias" or kind == "ln_b":
+        return ("normal", 0.0)
+    if kind == "ln_w":
+        return ("affine", (1.0, 0.0))
+    if kind in ("table", "pos"):
+        return ("normal", 0.02)
+    return _KIND_INIT[kind]
+
+
 def _tensor_rng(seed: int, name: str) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64([int(seed), zlib.crc32(name.encode())]))
 
 
-def synthetic_tensor(cfg: MAConfig, name: str, shape: Tuple[int, ...], kind: str, seed: int = 1234) -> np.ndarray:
+def synthetic_tensor(cfg: MAConfig, name: str, shape: Tuple[int, ...], kind: str, seed: int = 1234, init: str = "default") -> np.ndarray:
     rng = _tensor_rng(seed, name)
-    dist, par = _KIND_INIT[kind]
+    dist, par = _hf_init(cfg, name, kind) if init == "hf" else _KIND_INIT[kind]
     x = rng.standard_normal(shape, dtype=np.float32)
     if dist == "fan":
         fan_in = shape[-1]
@@ -209,15 +227,16 @@ def synthetic_tensor(cfg: MAConfig, name: str, shape: Tuple[int, ...], kind: str
 
 
 def synthetic_items(cfg: MAConfig, seed: int = 1234, include_unused: bool = False,
-                    bert_fused: bool = False) -> Iterator[Tuple[str, np.ndarray]]:
+                    bert_fused: bool = False, init: str = "default") -> Iterator[Tuple[str, np.ndarray]]:
     """Yield (reference key, fp32 ndarray) one tensor at a time (the 350M layout is 2.4 GB in fp32)."""
+    assert init in ("default", "hf")
     for name, (shape, kind) in state_dict_spec(cfg, include_unused, bert_fused).items():
-        yield name, synthetic_tensor(cfg, name, shape, kind, seed)
+        yield name, synthetic_tensor(cfg, name, shape, kind, seed, init)
 
 
 def synthetic_state_dict(cfg: MAConfig, seed: int = 1234, include_unused: bool = False,
-                         bert_fused: bool = False) -> "OrderedDict[str, np.ndarray]":
-    return OrderedDict(synthetic_items(cfg, seed, include_unused, bert_fused))
+                         bert_fused: bool = False, init: str = "default") -> "OrderedDict[str, np.ndarray]":
+    return OrderedDict(synthetic_items(cfg, seed, include_unused, bert_fused, init))
 
 
 def load_safetensors_items(path: str) -> Iterator[Tuple[str, np.ndarray]]:

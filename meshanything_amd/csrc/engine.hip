@@ -1179,6 +1179,57 @@ int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, cons
     });
 }
 
+// ---- batched decode step kernels (gemm_decode.hpp) --------------------------------------------------------------------
+int ma_op_gemm_dec(const void* W, const float* bias, const void* xb, const float* res, float* y, void* yb, int N, int K, int B, int act, int ksplit,
+                   void* stream) {
+    return guarded(nullptr, [&] {
+        if (!W || !xb || (!y && !yb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_dec: null pointer");
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(W); a.bias = bias; a.xb = reinterpret_cast<const bf16_t*>(xb); a.xb_stride = K;
+        a.res = res; a.res_stride = N; a.y = y; a.y_stride = N; a.yb = reinterpret_cast<bf16_t*>(yb); a.yb_stride = N;
+        a.N = N; a.K = K; a.B = B; a.act = act; a.epi = EPI_PLAIN; a.ksplit = ksplit;
+        hipError_t r = launch_gemm_dec(a, reinterpret_cast<hipStream_t>(stream));
+        if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_dec: ") + hipGetErrorString(r));
+    });
+}
+
+int ma_op_gemm_dec_qkv(const void* W, const float* bias, const void* xb, float* q, void* kcache, void* vcache, int H, int max_seq, int pos, int B,
+                       size_t kv_row_stride, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!W || !xb || !q || !kcache || !vcache || pos < 0 || pos >= max_seq) throw MaError(MA_ERR_INVALID, "ma_op_gemm_dec_qkv: bad arguments");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        DecState* st = nullptr;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st), (size_t)B * sizeof(DecState)));
+        try {
+            HIP_CHECK(hipMemsetAsync(st, 0, (size_t)B * sizeof(DecState), s));
+            hipLaunchKernelGGL(set_pos_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, st, 1, pos, 5, B);
+            HIP_CHECK(hipGetLastError());
+            GemmDecArgs a{};
+            a.W = reinterpret_cast<const bf16_t*>(W); a.bias = bias; a.xb = reinterpret_cast<const bf16_t*>(xb); a.xb_stride = H;
+            a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1; a.epi = EPI_QKV;
+            a.kcache = kcache; a.vcache = vcache; a.kv_row_stride = kv_row_stride; a.H = H; a.max_seq = max_seq; a.st = st;
+            hipError_t r = launch_gemm_dec(a, s);
+            if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("ma_op_gemm_dec_qkv: ") + hipGetErrorString(r));
+            HIP_CHECK(hipStreamSynchronize(s));
+        } catch (...) { (void)hipFree(st); throw; }
+        HIP_CHECK(hipFree(st));
+    });
+}
+
+int ma_op_rows_prologue(int pro, const float* x, int nparts, int B, const float* bias, const float* res, const float* ln_g, const float* ln_b, float ln_eps,
+                        const float* attn_ws, int attn_heads, float* xn_out, void* xb_out, int K, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!xb_out || (pro != PRO_ATTN && !x) || (pro == PRO_ATTN && !attn_ws) || (pro == PRO_LN && (!ln_g || !ln_b)))
+            throw MaError(MA_ERR_INVALID, "ma_op_rows_prologue: null pointer");
+        RowsProArgs a{};
+        a.x = x; a.x_stride = K; a.nparts = nparts < 1 ? 1 : nparts; a.B = B; a.bias = bias; a.res = res; a.res_stride = K;
+        a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.attn_ws = attn_ws; a.attn_ws_stride = attn_workspace_floats(attn_heads); a.attn_heads = attn_heads;
+        a.xn_out = xn_out; a.xn_stride = K; a.xb = reinterpret_cast<bf16_t*>(xb_out); a.xb_stride = K; a.K = K;
+        hipError_t r = launch_rows_prologue(a, pro, B, reinterpret_cast<hipStream_t>(stream));
+        if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_rows_prologue: ") + hipGetErrorString(r));
+    });
+}
+
 size_t ma_decode_attention_workspace_bytes(int H) {
     if (H < 1) return 0;
     return attn_workspace_floats(H) * sizeof(float);

@@ -1,0 +1,118 @@
+"""Fidelity of the benchmarked precision mode (bf16 engine) against the fp32 oracle -- REPORT-ONLY numbers (SURVEY.md 7,
+"hard parts (iii)"): the bf16-policy oracle mirrors the engine's rounding points, so token identity with it says nothing about
+how far bf16 greedy decoding drifts from the fp32 reference arithmetic.  These tests teacher-force the fp32 oracle on the bf16
+engine's own token stream and print: the first step where the fp32 argmax differs, the agreement rate, the fp32 top-1/top-2
+margin distribution, and the margins at the disagreeing steps.  Also: the same under HF-style N(0, 0.02) initialisation, and
+BASELINE.json config 3's synthetic sphere clouds run through the parity checker (ambiguous-step counts instead of swapping the
+inputs for easier ones).  The only assertions are sanity bounds that any correct engine meets."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from meshanything_amd.config import MAConfig, DTYPE_BF16
+from conftest import cached_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _mouse(golden_dir):
+    return torch.from_numpy(dict(np.load(os.path.join(golden_dir, "dataset.npz")))["mouse_norm"])[None]
+
+
+def _report(tag, oracle, prefix, toks, suppress_eos=True):
+    logits = oracle.teacher_forced_logits(prefix, toks)
+    if suppress_eos:
+        logits[:, 1] = float("-inf")
+    n = toks.shape[0]
+    top2 = torch.topk(logits[:n].float(), 2, dim=-1)
+    agree = top2.indices[:, 0] == toks
+    margin = top2.values[:, 0] - top2.values[:, 1]                         # fp32 top-1 / top-2 gap at every step
+    dis = (~agree).nonzero().flatten()
+    first = int(dis[0]) if dis.numel() else None
+    # margin by which the fp32 oracle prefers its own token over the engine's, at the disagreeing steps
+    lost = (top2.values[dis, 0] - logits[dis, toks[dis]]) if dis.numel() else torch.zeros(0)
+    q = torch.quantile(margin, torch.tensor([0.001, 0.01, 0.1, 0.5, 0.9]))
+    print(f"[fidelity {tag}] {n} tokens teacher-forced through the fp32 oracle: argmax agreement {float(agree.float().mean()) * 100:.3f} % "
+          f"({int(dis.numel())} steps differ), first divergence at step {first}; fp32 top-1/top-2 margin quantiles "
+          f"0.1% {q[0]:.4f} | 1% {q[1]:.4f} | 10% {q[2]:.4f} | 50% {q[3]:.4f} | 90% {q[4]:.4f}; "
+          f"margin lost at the differing steps: max {float(lost.max()) if lost.numel() else 0:.4f}, median {float(lost.median()) if lost.numel() else 0:.4f}")
+    return float(agree.float().mean()), first, margin, lost
+
+
+def test_fidelity_bf16_stream_vs_fp32_oracle(golden_dir):
+    """BASELINE.json configs[1]: mouse.npy, 350M shape, bf16 engine, greedy, all 7202 tokens of the 800-face cap."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle
+    cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=1)
+    sd = cached_state_dict(cfg)
+    eng = Engine(cfg)
+    eng.load_weights(sd.items())
+    x = _mouse(golden_dir)
+    out = eng.forward(x.cuda(), suppress_eos=True)
+    toks = out["tokens"][0].cpu()
+    assert toks.shape[0] == cfg.max_new_tokens
+    ofp = Oracle(cfg, sd, "fp32")
+    prefix32 = ofp.process_point_feature(ofp.encode_latents(x))             # what the fp32 reference arithmetic feeds the decoder
+    n = int(os.environ.get("MA_TEST_FIDELITY_TOKENS", str(cfg.max_new_tokens)))
+    rate, first, margin, lost = _report("bf16 engine vs fp32 oracle, default init", ofp, prefix32, toks[:n])
+    # sanity only: a correct bf16 engine agrees with fp32 on the overwhelming majority of teacher-forced steps, and where it
+    # does not, fp32 itself was nearly undecided
+    assert rate > 0.97
+    assert lost.numel() == 0 or float(lost.max()) < 0.25
+    eng.close()
+
+
+def test_fidelity_hf_style_initialisation(golden_dir):
+    """The same report under N(0, 0.02) weights (what transformers' constructors leave): margins ~5x smaller, report only."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle, verify_greedy_stream
+    cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=1)
+    sd = cached_state_dict(cfg, init="hf")
+    eng = Engine(cfg)
+    eng.load_weights(sd.items())
+    x = _mouse(golden_dir)
+    n = int(os.environ.get("MA_TEST_FIDELITY_HF_TOKENS", "1500"))
+    out = eng.forward(x.cuda(), suppress_eos=True, max_new_tokens=n)
+    toks = out["tokens"][0].cpu()
+    ofp = Oracle(cfg, sd, "fp32")
+    prefix32 = ofp.process_point_feature(ofp.encode_latents(x))
+    rate, first, margin, lost = _report("bf16 engine vs fp32 oracle, HF-style init", ofp, prefix32, toks)
+    obf = Oracle(cfg, sd, "bf16")
+    v = verify_greedy_stream(obf, obf.process_point_feature(out["latents"].cpu()), toks, 2e-2, suppress_eos=True)
+    print(f"[fidelity HF-style init] same stream vs the bf16-policy oracle (engine's own prefix): {v}")
+    assert v["hard"] == [], v                                               # the like-for-like check still holds
+    assert rate > 0.5
+    eng.close()
+
+
+def test_fidelity_config3_sphere_clouds():
+    """BASELINE.json config 3's inputs as specified (synthetic unit-sphere clouds): the parity checker's verdict on them --
+    ambiguous steps counted, nothing swapped out."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle, normalize_pc, verify_greedy_stream
+    cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=4)
+    sd = cached_state_dict(cfg)
+    eng = Engine(cfg)
+    eng.load_weights(sd.items())
+
+    def sphere(seed):
+        g = torch.Generator().manual_seed(seed)
+        d = torch.randn(cfg.n_points, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        r = 0.3 + 0.7 * torch.rand(cfg.n_points, 1, generator=g)
+        return normalize_pc(torch.cat([d * r, d], dim=-1).numpy().astype(np.float32))
+    x = torch.from_numpy(np.stack([sphere(s) for s in range(4)]))
+    obf = Oracle(cfg, sd, "bf16")
+    prefix = obf.process_point_feature(obf.encode_latents(x))
+    n = 160
+    toks, lengths = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+    rows = []
+    for b in range(4):
+        v = verify_greedy_stream(obf, prefix[b:b + 1], toks[b].cpu(), 2e-2, suppress_eos=True)
+        rows.append(v)
+        assert v["hard"] == [], v
+    print("[fidelity config-3 sphere clouds] batch 4 x %d tokens vs the bf16-policy oracle: ambiguous steps %s, median top-1/top-2 gap %s, min gap %s"
+          % (n, [r["ambiguous"] for r in rows], ["%.4f" % r["median_top_gap"] for r in rows], ["%.5f" % r["min_top_gap"] for r in rows]))
+    eng.close()

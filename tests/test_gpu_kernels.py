@@ -203,3 +203,107 @@ def test_decode_attention(lib, kvdtype, length, max_seq, H):
     assert not torch.isnan(outs[0]).any()
     assert float((outs[0] - ref).abs().max()) < 2e-5
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+# ---------------------------------------------------------------------------------------------- batched decode step kernels
+@pytest.mark.parametrize("B", [4, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K,ksplit,act", [(3072, 1024, 1, 0), (4096, 1024, 1, 1), (1024, 1024, 4, 0), (1024, 4096, 4, 0), (1024, 4096, 1, 0),
+                                           (8195, 1024, 1, 0), (384, 128, 1, 1), (128, 512, 4, 0)])
+def test_gemm_dec(lib, B, N, K, ksplit, act):
+    """Skinny bf16 MFMA GEMM of the batched decode step (gemm_decode.hpp) against fp64 torch: every batch-tile count (1-4),
+    whole-K and split-K launches (split launches return raw partial sums, summed here), bias / ReLU / residual epilogue,
+    fp32 and bf16 outputs."""
+    g = torch.Generator().manual_seed(B + N + 3 * K + ksplit)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02).to(torch.bfloat16)
+    X = (torch.randn(B, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(B, N, generator=g)
+    ref = X.double() @ W.double().t()
+    dev = "cuda"
+    Wd, Xd = W.to(dev).contiguous(), X.to(dev).contiguous()
+    if ksplit > 1:
+        y = torch.full((ksplit, B, N), float("nan"), device=dev)
+        _chk(lib, lib.ma_op_gemm_dec(_p(Wd), None, _p(Xd), None, _p(y), None, N, K, B, 0, ksplit, _stream()))
+        torch.cuda.synchronize()
+        assert not torch.isnan(y).any()
+        assert _relerr(y.sum(dim=0), ref.float()) < 2e-5
+        return
+    full = ref + bias.double()
+    if act == 1:
+        full = torch.relu(full)
+    full = (full + res.double()).float()
+    bd, rd = bias.to(dev), res.to(dev).contiguous()
+    y = torch.full((B, N), float("nan"), device=dev)
+    yb = torch.zeros(B, N, dtype=torch.bfloat16, device=dev)
+    _chk(lib, lib.ma_op_gemm_dec(_p(Wd), _p(bd), _p(Xd), _p(rd), _p(y), _p(yb), N, K, B, act, 1, _stream()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any()
+    assert _relerr(y, full) < 2e-5, _relerr(y, full)
+    assert torch.equal(yb.cpu(), y.cpu().to(torch.bfloat16))          # the bf16 output is the rounded fp32 output
+
+
+@pytest.mark.parametrize("B", [4, 17, 64])
+def test_gemm_dec_qkv_epilogue(lib, B):
+    """q rows -> fp32 vector per batch row; k / v rows -> that row's cache planes at `pos` (bf16), nothing else touched."""
+    H, heads, max_seq, pos = 1024, 16, 300, 271
+    g = torch.Generator().manual_seed(B)
+    W = (torch.randn(3 * H, H, generator=g) / math.sqrt(H)).to(torch.bfloat16)
+    X = torch.randn(B, H, generator=g).to(torch.bfloat16)
+    bias = torch.randn(3 * H, generator=g) * 0.1
+    ref = (X.double() @ W.double().t() + bias.double()).float()
+    dev = "cuda"
+    stride = heads * max_seq * 64
+    kc = torch.full((B, heads, max_seq, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    vc = torch.full((B, heads, max_seq, 64), -7.0, dtype=torch.bfloat16, device=dev)
+    q = torch.full((B, H), float("nan"), device=dev)
+    Wd, Xd, bd = W.to(dev).contiguous(), X.to(dev).contiguous(), bias.to(dev)
+    _chk(lib, lib.ma_op_gemm_dec_qkv(_p(Wd), _p(bd), _p(Xd), _p(q), _p(kc), _p(vc), H, max_seq, pos, B, stride, _stream()))
+    torch.cuda.synchronize()
+    assert _relerr(q, ref[:, :H]) < 2e-5
+    kref = ref[:, H:2 * H].reshape(B, heads, 64).to(torch.bfloat16)
+    vref = ref[:, 2 * H:].reshape(B, heads, 64).to(torch.bfloat16)
+    kgot, vgot = kc[:, :, pos].cpu(), vc[:, :, pos].cpu()
+    # bf16 rounding of values that differ by fp32 summation order may land one ulp apart
+    assert float((kgot.float() - kref.float()).abs().max()) <= 2 ** -6 and float((vgot.float() - vref.float()).abs().max()) <= 2 ** -6
+    assert float((kgot.float() - kref.float()).abs().mean()) < 1e-4
+    kc[:, :, pos] = 7.0
+    vc[:, :, pos] = -7.0
+    assert bool((kc == 7.0).all()) and bool((vc == -7.0).all())       # no other position was written
+
+
+@pytest.mark.parametrize("B", [4, 17, 64])
+@pytest.mark.parametrize("pro", [0, 1, 2], ids=["plain", "ln", "attn"])
+def test_rows_prologue(lib, B, pro):
+    """Per-row prologue of the batched step: split-K partial sum + bias + residual (+ LayerNorm), or the merge of the
+    split-KV attention partials; fp32 and bf16 outputs."""
+    K, heads = 1024, 16
+    g = torch.Generator().manual_seed(B + pro)
+    dev = "cuda"
+    xb = torch.zeros(B, K, dtype=torch.bfloat16, device=dev)
+    xn = torch.full((B, K), float("nan"), device=dev)
+    if pro == 2:
+        m = torch.randn(B, heads, 16, generator=g) * 2
+        l = torch.rand(B, heads, 16, generator=g) + 0.5
+        o = torch.randn(B, heads, 16, 64, generator=g)
+        ws = torch.cat([torch.stack([m, l], dim=-1).reshape(B, -1), o.reshape(B, -1)], dim=1).contiguous()      # ML[h][c][2] then O[h][c][64]
+        wmax = m.max(dim=-1, keepdim=True).values
+        f = torch.exp(m.double() - wmax.double())
+        ref = ((o.double() * f[..., None]).sum(dim=2) / (l.double() * f).sum(dim=2)[..., None]).reshape(B, K).float()
+        wsd = ws.to(dev)
+        _chk(lib, lib.ma_op_rows_prologue(2, None, 1, B, None, None, None, None, 0.0, _p(wsd), heads, _p(xn), _p(xb), K, _stream()))
+    else:
+        nparts = 4
+        parts = torch.randn(nparts, B, K, generator=g)
+        bias = torch.randn(K, generator=g) * 0.1
+        res = torch.randn(B, K, generator=g) + 3.0                        # a large mean: the one-pass statistics must not care
+        lg = 1 + 0.1 * torch.randn(K, generator=g)
+        lb = 0.05 * torch.randn(K, generator=g)
+        x = parts.double().sum(dim=0) + bias.double() + res.double()
+        ref = (torch.nn.functional.layer_norm(x, (K,), lg.double(), lb.double(), 1e-5) if pro == 1 else x).float()
+        pd, bd, rd, lgd, lbd = parts.to(dev).contiguous(), bias.to(dev), res.to(dev).contiguous(), lg.to(dev), lb.to(dev)
+        _chk(lib, lib.ma_op_rows_prologue(pro, _p(pd), nparts, B, _p(bd), _p(rd), _p(lgd) if pro == 1 else None, _p(lbd) if pro == 1 else None, 1e-5,
+                                           None, heads, _p(xn), _p(xb), K, _stream()))
+    torch.cuda.synchronize()
+    assert not torch.isnan(xn).any()
+    assert float((xn.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(xb.cpu(), xn.cpu().to(torch.bfloat16))
