@@ -190,6 +190,10 @@ MA_API int  ma_op_gemv(int wdtype, const void *W, const float *bias, const float
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + R[M,N]; K % 32 == 0; impl 0 = MFMA, 1 = plain VALU reference kernel */
 MA_API int  ma_op_gemm(int wdtype, int impl, const float *A, int lda, const void *W, const float *bias, const float *R, int ldr,
                        float *C, int ldc, int M, int N, int K, int act, void *stream);
+/* the same GEMM on the bf16 policy's native operands (csrc/gemm_tile.hpp: 128x128x64 LDS-DMA-staged MFMA tile): A (M, lda) bf16,
+ * W (N, K) bf16; fp32 output C and / or bf16 output Cb (either may be NULL); K % 32 == 0, lda % 8 == 0, ld* % 4 == 0 */
+MA_API int  ma_op_gemm_bf16(const void *A, int lda, const void *W, const float *bias, const float *R, int ldr, float *C, int ldc,
+                            void *Cb, int ldcb, int M, int N, int K, int act, void *stream);
 MA_API int  ma_op_layernorm(const float *x, int ldx, const float *g, const float *b, float eps, float *y, int ldy,
                             int rows, int D, void *stream);
 /* O[b,q,h*64+d] = softmax(Q K^T * scale) V, head_dim 64, fp32 in/out; strides in elements; round_bf16 rounds q,k,v */

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ma_forward": (_I, [_P, _P, _I, _I, C.POINTER(SampleCfg), _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P]),
     "ma_op_gemv": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ma_op_gemm": (_I, [_I, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "ma_op_gemm_bf16": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "ma_op_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _P]),
     "ma_op_attention": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "ma_op_decode_attention": (_I, [_I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

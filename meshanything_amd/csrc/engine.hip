@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "gemm.hpp"
 #include "gemm_decode.hpp"
+#include "gemm_tile.hpp"
 #include "gemv.hpp"
 #include "misc.hpp"
 #include "persist.hpp"
@@ -1137,11 +1138,32 @@ int ma_op_gemm(int wdtype, int impl, const float* A, int lda, const void* W, con
     return guarded(nullptr, [&] {
         if (!A || !W || !C) throw MaError(MA_ERR_INVALID, "ma_op_gemm: null pointer");
         GemmArgs g{A, lda, W, bias, R, ldr, C, ldc, M, N, K, act};
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         hipError_t r;
-        if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, impl, reinterpret_cast<hipStream_t>(stream));
-        else if (wdtype == MA_DTYPE_F32) r = launch_gemm<float>(g, impl, reinterpret_cast<hipStream_t>(stream));
+        if (wdtype == MA_DTYPE_BF16 && impl == 0) {
+            // the engine's bf16 GEMM takes bf16 activations (gemm_tile.hpp): round A first, as the producing kernel would have
+            bf16_t* Ab = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Ab), (size_t)M * K * sizeof(bf16_t)));
+            hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(ceil_div(M * K, 256)), dim3(256), 0, s, A, lda, Ab, K, M, K);
+            GemmTArgs t{Ab, K, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, nullptr, 0, M, N, K, act};
+            r = launch_gemm_tile(t, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(Ab);
+        } else if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, impl == 2 ? 0 : impl, s);
+        else if (wdtype == MA_DTYPE_F32) r = launch_gemm<float>(g, impl, s);
         else throw MaError(MA_ERR_INVALID, "ma_op_gemm: wdtype");
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("ma_op_gemm: ") + hipGetErrorString(r));
+    });
+}
+
+// the bf16 policy's dense GEMM on its native operands (gemm_tile.hpp): A (M, lda) bf16, W (N, K) bf16; fp32 output C and / or bf16 output Cb
+int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, const float* R, int ldr, float* C, int ldc, void* Cb, int ldcb, int M, int N,
+                    int K, int act, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!A || !W || (!C && !Cb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_bf16: null pointer");
+        GemmTArgs t{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, reinterpret_cast<bf16_t*>(Cb), ldcb, M, N, K, act};
+        hipError_t r = launch_gemm_tile(t, reinterpret_cast<hipStream_t>(stream));
+        if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_bf16: ") + hipGetErrorString(r));
     });
 }
 

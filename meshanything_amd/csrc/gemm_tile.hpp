@@ -1,0 +1,180 @@
+// Dense GEMM of the bf16 policy: C[M,N] = act(A[M,K] . W[N,K]^T + bias) + R with BOTH operands bf16 in HBM.
+//
+// Reference call sites: every nn.Linear of the point encoder (transformer_blocks.py, sal_perceiver.py:45,90,273-275,383-396),
+// the decoder prefill ([3p] OPTDecoderLayer at S = 257, shape_opt.py:403-410) and the detokenizer (meshanything.py:42-80),
+// with the samples of a batch stacked along M (M = B x 257 | B x 4096 | B x 1057).
+//
+// Structure (MI355X guide section 5, the 128 x 128 LDS-staged tile with global_load_lds):
+//   * block tile 128 (M) x 128 (N) x 64 (K), 4 waves as 2 x 2, each wave a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_bf16
+//     tiles (16 fp32x4 accumulators); a 64 x 64 x 32 variant serves the small problems (M <= 64, pre_kl N = 64, tiny shapes);
+//   * both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip), two
+//     LDS stages: the loads of K-tile t + 1 fly under the MFMAs of K-tile t, one barrier per K-tile;
+//   * the LDS image is lane-linear (the DMA cannot scatter), so the bank-conflict swizzle is applied to the SOURCE address:
+//     16-byte chunk c of tile row r is fetched into slot c ^ (r & 7) and read back from there by ds_read_b128;
+//   * the W tile is the MFMA A operand and the activation tile the B operand, so a lane ends up with FOUR CONSECUTIVE n of one
+//     output row m: bias / residual / outputs move as 16-byte (fp32) or 8-byte (bf16) vectors;
+//   * epilogue fused: bias, ReLU / GELU(erf), fp32 residual; the result is stored as fp32 (residual stream, LayerNorm input)
+//     or as bf16 (the next GEMM's / attention's operand -- the policy's rounding point moves from that consumer's load to here,
+//     same value), so activations cross HBM once, in 2 bytes.
+// Accumulation order along K is k-ascending in 32-wide MFMA steps, exactly as the 64 x 64 kernel of round 1 (gemm.hpp).
+// Algorithmic FLOPs: 2 M N K.
+#pragma once
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace ma {
+
+struct GemmTArgs {
+    const bf16_t* A; int lda;       // [M][lda] bf16, K contiguous
+    const bf16_t* W;                // [N][K] bf16
+    const float* bias;              // [N] or null
+    const float* R; int ldr;        // fp32 residual [M][ldr] or null (may alias C)
+    float* C; int ldc;              // fp32 output or null
+    bf16_t* Cb; int ldcb;           // bf16 output or null
+    int M, N, K, act;
+};
+
+__device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// BM x BN x BK block tile, 4 waves as 2 x 2.  LDS: 2 stages x (BM + BN) rows x BK bf16.
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
+    constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CH;                      // tile rows one DMA instruction covers
+    constexpr int ROWB = BK * 2;                      // bytes per tile row
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
+    constexpr int TM = BM / 32, TN = BN / 32;         // 16 x 16 MFMA tiles per wave along m / n
+    extern __shared__ __attribute__((aligned(16))) char gt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const unsigned lds0 = (unsigned)(size_t)gt_smem;
+
+    // ---- DMA addressing: instruction p of an operand covers tile rows p * RPI .. + RPI - 1; lane -> (row, slot) -----------
+    const int drow = lane / CH, dslot = lane % CH;
+    auto issue = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+        const unsigned sbase = lds0 + (unsigned)stage * STAGE;
+#pragma unroll
+        for (int p = w; p < BM / RPI; p += 4) {
+            const int r = p * RPI + drow;
+            const int m = min(bm + r, g.M - 1);
+            const bf16_t* src = g.A + (size_t)m * g.lda + k0 + ((dslot ^ (r & (CH - 1))) * 8);
+            gt_glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)p * 1024u));
+        }
+#pragma unroll
+        for (int p = w; p < BN / RPI; p += 4) {
+            const int r = p * RPI + drow;
+            const int n = min(bn + r, g.N - 1);
+            const bf16_t* src = g.W + (size_t)n * g.K + k0 + ((dslot ^ (r & (CH - 1))) * 8);
+            gt_glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)A_BYTES + (unsigned)p * 1024u));
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, kg = lane >> 4;          // fragment row, 8-element k group
+    const int nk = g.K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of K-tile kt have landed ...
+        __syncthreads();                                       // ... and everyone's; the other stage is free (its readers are done)
+        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        const char* sa = gt_smem + stage * STAGE;
+        const char* sw = sa + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            bf16x8_t wf[TN], xf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * (BN / 2) + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sw + r * ROWB + (((s * 4 + kg) ^ (r & (CH - 1))) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * (BM / 2) + j * 16 + fr;
+                xf[j] = *reinterpret_cast<const bf16x8_t*>(sa + r * ROWB + (((s * 4 + kg) ^ (r & (CH - 1))) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds n = n0 .. n0 + 3 of row m ------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int n0 = bn + wn * (BN / 2) + i * 16 + kg * 4;
+        if (n0 >= g.N) continue;
+        const bool full = n0 + 3 < g.N;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+            if (full) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0);
+            else { b4.x = g.bias[n0]; if (n0 + 1 < g.N) b4.y = g.bias[n0 + 1]; if (n0 + 2 < g.N) b4.z = g.bias[n0 + 2]; }
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = bm + wm * (BM / 2) + j * 16 + fr;
+            if (m >= g.M) continue;
+            f32x4 v = acc[i][j];
+            v.x = apply_act(v.x + b4.x, g.act); v.y = apply_act(v.y + b4.y, g.act);
+            v.z = apply_act(v.z + b4.z, g.act); v.w = apply_act(v.w + b4.w, g.act);
+            if (full) {
+                if (g.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(g.R + (size_t)m * g.ldr + n0); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                if (g.C) *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + n0) = v;
+                if (g.Cb) {
+                    u32x2 pk;
+                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+                    *reinterpret_cast<u32x2*>(g.Cb + (size_t)m * g.ldcb + n0) = pk;
+                }
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int r = 0; r < 4 && n0 + r < g.N; ++r) {
+                    float t = vv[r];
+                    if (g.R) t += g.R[(size_t)m * g.ldr + n0 + r];
+                    if (g.C) g.C[(size_t)m * g.ldc + n0 + r] = t;
+                    if (g.Cb) g.Cb[(size_t)m * g.ldcb + n0 + r] = f2bf(t);
+                }
+            }
+        }
+    }
+}
+
+// 16-byte DMA sources and vector epilogue accesses need: lda % 8 == 0, K % 32 == 0, ldc / ldr % 4 == 0, ldcb % 4 == 0
+inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
+    static bool attr = false;
+    constexpr int BIG = 2 * (128 + 128) * 64 * 2;      // 64 KiB
+    if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<128, 128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, BIG);
+        if (r != hipSuccess) return r;
+        attr = true;
+    }
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 64)
+        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), BIG, s, g);
+    else
+        hipLaunchKernelGGL((gemm_tile_kernel<64, 64, 32>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 2 * (64 + 64) * 32 * 2, s, g);
+    return hipGetLastError();
+}
+
+// fp32 -> bf16 rows (kernel-level entry point ma_op_gemm with a bf16 weight and an fp32 activation matrix; small utility elsewhere)
+__global__ void f32_to_bf16_rows_kernel(const float* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    dst[(size_t)i * ldd + n] = f2bf(src[(size_t)i * lds + n]);
+}
+
+}  // namespace ma

@@ -73,11 +73,13 @@ def test_gemv(lib, wdtype, N, K, variant):
 
 
 @pytest.mark.parametrize("wdtype", [0, 1], ids=["f32", "bf16"])
-@pytest.mark.parametrize("impl", [0, 1], ids=["mfma", "valu"])
+@pytest.mark.parametrize("impl", [0, 1, 2], ids=["mfma", "valu", "mfma64"])
 @pytest.mark.parametrize("M,N,K,act,use_res", [(257, 768, 768, 0, True), (4096, 768, 64, 0, False), (257, 2304, 768, 0, False),
                                                (1057, 3072, 768, 2, False), (17, 128, 128, 1, True), (1, 1024, 768, 0, False),
                                                (100, 96, 32, 0, False), (256, 64, 3072, 0, True)])
 def test_gemm(lib, wdtype, impl, M, N, K, act, use_res):
+    if impl == 2 and wdtype == 0:
+        pytest.skip("impl 2 = the 64x64 register-staged bf16 kernel of round 1")
     g = torch.Generator().manual_seed(M + 3 * N + 5 * K + wdtype)
     # asymmetric data so that a transposed fragment layout cannot pass
     A = torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5
@@ -307,3 +309,53 @@ def test_rows_prologue(lib, B, pro):
     assert not torch.isnan(xn).any()
     assert float((xn.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert torch.equal(xb.cpu(), xn.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res,out", [(4112, 3072, 1024, 0, False, "bf16"), (4112, 1024, 1024, 0, True, "f32"), (4112, 4096, 1024, 1, False, "bf16"),
+                                                   (4112, 1024, 4096, 0, True, "f32"), (2056, 768, 768, 2, False, "both"), (65536, 1536, 768, 0, False, "bf16"),
+                                                   (257, 2304, 768, 0, False, "bf16"), (130, 200, 192, 0, True, "both"), (1, 1024, 768, 0, False, "f32"),
+                                                   (16912, 768, 3072, 0, True, "f32"), (300, 64, 768, 0, False, "f32"), (77, 1152, 96, 0, False, "f32")])
+def test_gemm_bf16_tile(lib, M, N, K, act, use_res, out):
+    """The bf16 policy's dense GEMM (gemm_tile.hpp) on its native bf16 operands at the batched dense-phase shapes (B x 257,
+    B x 4096, B x 1057 rows), ragged edges, both tile variants; fp32 and bf16 outputs; reports TFLOP/s."""
+    g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
+    A = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g) * 0.1
+    R = torch.randn(M, N, generator=g)
+    dev = "cuda"
+    Ad, Wd, bd, Rd = A.to(dev), W.to(dev), bias.to(dev), R.to(dev)
+    ref = Ad.double() @ Wd.double().t() + bd.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if use_res:
+        ref = ref + Rd.double()
+    ref = ref.float()
+    C = torch.full((M, N), float("nan"), device=dev) if out in ("f32", "both") else None
+    Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev) if out in ("bf16", "both") else None
+
+    def run():
+        _chk(lib, lib.ma_op_gemm_bf16(_p(Ad), K, _p(Wd), _p(bd), _p(Rd) if use_res else None, N, _p(C), N, _p(Cb), N, M, N, K, act, _stream()))
+    run()
+    torch.cuda.synchronize()
+    scale = max(1e-6, float(ref.abs().max()))
+    if C is not None:
+        assert not torch.isnan(C).any()
+        assert float((C - ref).abs().max()) / scale < 3e-5
+    if Cb is not None:
+        assert float((Cb.float() - ref).abs().max()) / scale < 6e-3          # bf16 output: half an ulp of the largest value
+        if C is not None:
+            assert torch.equal(Cb, C.to(torch.bfloat16))
+    if M * N * K >= 1 << 30:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(3):
+            run()
+        ev[0].record()
+        for _ in range(20):
+            run()
+        ev[1].record()
+        torch.cuda.synchronize()
+        us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
+        print(f"[gemm_tile] M {M} N {N} K {K} act {act} res {use_res} out {out}: {us:.1f} us = {2.0 * M * N * K / us * 1e-6:.1f} TFLOP/s")
