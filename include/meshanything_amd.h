@@ -175,6 +175,9 @@ MA_API int  ma_get_codes(ma_engine *e, const int64_t *ids, int B, float *codes, 
 /* replaces: get_codes (meshanything.py:178-212) + tokenizer(ids, codes, point_feature=latents) (50-80).
  *   coords (B, n_max_faces, 3, 3) fp32, NaN rows = invalid faces */
 MA_API int  ma_detokenize(ma_engine *e, const int64_t *ids, const float *latents, int B, float *coords, void *stream);
+/* the same with the caller's `input_embeds` (B, 3*n_max_faces, codebook_dim) fp32 as the face codes -- the reference's
+ * tokenizer(input_ids, input_embeds, point_feature=...) signature (meshanything.py:50-55); codes == NULL: ma_detokenize */
+MA_API int  ma_detokenize_embeds(ma_engine *e, const int64_t *ids, const float *codes, const float *latents, int B, float *coords, void *stream);
 
 /* replaces: MeshAnything.forward(pc_normal, sampling) (meshanything.py:134-176): encode -> generate ->
  * postprocess -> detokenize.  `tokens` / `ids` / `latents` may be NULL.  Synchronises. */

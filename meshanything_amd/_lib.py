@@ -66,6 +66,7 @@ SIGNATURES = {
     "ma_generate": (_I, [_P, _P, _I, C.POINTER(SampleCfg), _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "ma_postprocess_tokens": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "ma_detokenize": (_I, [_P, _P, _P, _I, _P, _P]),
+    "ma_detokenize_embeds": (_I, [_P, _P, _P, _P, _I, _P, _P]),
     "ma_forward": (_I, [_P, _P, _I, _I, C.POINTER(SampleCfg), _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P]),
     "ma_op_gemv": (_I, [_I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
     "ma_op_gemm": (_I, [_I, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -15,10 +15,12 @@
 namespace ma {
 
 struct AttnArgs {
-    const float* Q; int q_rs, q_hs;     // element strides: row (sequence position), head
-    const float* K; int k_rs, k_hs;
-    const float* V; int v_rs, v_hs;
-    float* O; int o_rs;                 // O[q * o_rs + h*64 + d]
+    // element type of Q / K / V / O: float for attention_kernel and attention_mfma_kernel<float>, bf16 for
+    // attention_mfma_kernel<bf16_t> (the engine's bf16 policy: activations are produced and consumed as bf16)
+    const void* Q; int q_rs, q_hs;      // element strides: row (sequence position), head
+    const void* K; int k_rs, k_hs;
+    const void* V; int v_rs, v_hs;
+    void* O; int o_rs;                  // O[q * o_rs + h*64 + d]
     int Sq, Sk, H;
     float scale;
     int causal_offset;                  // < 0: full attention; else query i sees keys <= causal_offset + i
@@ -35,13 +37,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int tid = threadIdx.x, r = tid >> 2, c = tid & 3;
     const int h = blockIdx.y;
     const int q0 = blockIdx.x * 64;
-    a.Q += blockIdx.z * a.q_bs; a.K += blockIdx.z * a.k_bs; a.V += blockIdx.z * a.v_bs; a.O += blockIdx.z * a.o_bs;
+    const float* Qf = reinterpret_cast<const float*>(a.Q) + blockIdx.z * a.q_bs; const float* Kf = reinterpret_cast<const float*>(a.K) + blockIdx.z * a.k_bs;
+    const float* Vf = reinterpret_cast<const float*>(a.V) + blockIdx.z * a.v_bs; float* Of = reinterpret_cast<float*>(a.O) + blockIdx.z * a.o_bs;
     const int m = q0 + r;
     const bool row_ok = m < a.Sq;
 
     float q[64];
     {
-        const float* qp = a.Q + (size_t)(row_ok ? m : 0) * a.q_rs + (size_t)h * a.q_hs;
+        const float* qp = Qf + (size_t)(row_ok ? m : 0) * a.q_rs + (size_t)h * a.q_hs;
 #pragma unroll
         for (int d = 0; d < 64; d += 4) {
             f32x4 t = *reinterpret_cast<const f32x4*>(qp + d);
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             const int kp = kv0 + spos;
             f32x4 kk[4], vv[4];
             if (kp < a.Sk) {
-                const float* kptr = a.K + (size_t)kp * a.k_rs + (size_t)h * a.k_hs + sd;
-                const float* vptr = a.V + (size_t)kp * a.v_rs + (size_t)h * a.v_hs + sd;
+                const float* kptr = Kf + (size_t)kp * a.k_rs + (size_t)h * a.k_hs + sd;
+                const float* vptr = Vf + (size_t)kp * a.v_rs + (size_t)h * a.v_hs + sd;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { kk[i] = *reinterpret_cast<const f32x4*>(kptr + 4 * i); vv[i] = *reinterpret_cast<const f32x4*>(vptr + 4 * i); }
                 if (a.round_bf16) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         o[d] = t * inv;
     }
     if (row_ok) {
-        float* op = a.O + (size_t)m * a.o_rs + h * 64;
+        float* op = Of + (size_t)m * a.o_rs + h * 64;
 #pragma unroll
         for (int d = 0; d < 64; ++d)
             if ((d >> 4) == c) op[d] = o[d];
@@ -157,6 +160,8 @@ typedef __bf16 attn_bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int AM_LD = 72;                // bf16 elements per LDS row: 64 + 8 pad (144-byte rows keep ds_read_b128 aligned)
 
 
+// IT = element type of Q / K / V / O in HBM: float (rounded to bf16 while staging) or bf16_t (already rounded by the producer)
+template <typename IT>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AM_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * AM_LD];
@@ -164,23 +169,29 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m16 = lane & 15, kg = lane >> 4;
     const int h = blockIdx.y, q0 = blockIdx.x * 64;
-    a.Q += blockIdx.z * a.q_bs; a.K += blockIdx.z * a.k_bs; a.V += blockIdx.z * a.v_bs; a.O += blockIdx.z * a.o_bs;
+    const IT* Qp = reinterpret_cast<const IT*>(a.Q) + blockIdx.z * a.q_bs; const IT* Kp = reinterpret_cast<const IT*>(a.K) + blockIdx.z * a.k_bs;
+    const IT* Vp = reinterpret_cast<const IT*>(a.V) + blockIdx.z * a.v_bs; IT* Op = reinterpret_cast<IT*>(a.O) + blockIdx.z * a.o_bs;
+    // 8 consecutive elements -> packed bf16 (fp32 input: rounded here; bf16 input: one 16-byte load)
+    auto load8 = [](const IT* p, bool ok) -> u32x4 {
+        u32x4 pk = {0u, 0u, 0u, 0u};
+        if (ok) {
+            if constexpr (sizeof(IT) == 4) {
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(p), t1 = *reinterpret_cast<const f32x4*>(p + 4);
+                pk.x = (uint32_t)f2bf(t0.x) | ((uint32_t)f2bf(t0.y) << 16); pk.y = (uint32_t)f2bf(t0.z) | ((uint32_t)f2bf(t0.w) << 16);
+                pk.z = (uint32_t)f2bf(t1.x) | ((uint32_t)f2bf(t1.y) << 16); pk.w = (uint32_t)f2bf(t1.z) | ((uint32_t)f2bf(t1.w) << 16);
+            } else pk = *reinterpret_cast<const u32x4*>(p);
+        }
+        return pk;
+    };
 
     // Q fragments of this wave's 16 rows: lane (row m16, dims s*32 + kg*8 .. +8)
     attn_bf16x8_t qa[2];
     {
         const int qrow = q0 + w * 16 + m16;
         const bool ok = qrow < a.Sq;
-        const float* qp = a.Q + (size_t)(ok ? qrow : 0) * a.q_rs + (size_t)h * a.q_hs + kg * 8;
+        const IT* qp = Qp + (size_t)(ok ? qrow : 0) * a.q_rs + (size_t)h * a.q_hs + kg * 8;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            f32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-            if (ok) { t0 = *reinterpret_cast<const f32x4*>(qp + s2 * 32); t1 = *reinterpret_cast<const f32x4*>(qp + s2 * 32 + 4); }
-            u32x4 pk;
-            pk.x = (uint32_t)f2bf(t0.x) | ((uint32_t)f2bf(t0.y) << 16); pk.y = (uint32_t)f2bf(t0.z) | ((uint32_t)f2bf(t0.w) << 16);
-            pk.z = (uint32_t)f2bf(t1.x) | ((uint32_t)f2bf(t1.y) << 16); pk.w = (uint32_t)f2bf(t1.z) | ((uint32_t)f2bf(t1.w) << 16);
-            qa[s2] = __builtin_bit_cast(attn_bf16x8_t, pk);
-        }
+        for (int s2 = 0; s2 < 2; ++s2) qa[s2] = __builtin_bit_cast(attn_bf16x8_t, load8(qp + s2 * 32, ok));
     }
     f32x4 o[4];
 #pragma unroll
@@ -195,30 +206,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
         {
             const int kp = kv0 + skey;
-            f32x4 kk[4], vv[4];
-            if (kp < a.Sk) {
-                const float* kptr = a.K + (size_t)kp * a.k_rs + (size_t)h * a.k_hs + sd;
-                const float* vptr = a.V + (size_t)kp * a.v_rs + (size_t)h * a.v_hs + sd;
+            const bool kok = kp < a.Sk;
+            const IT* kptr = Kp + (size_t)(kok ? kp : 0) * a.k_rs + (size_t)h * a.k_hs + sd;
+            const IT* vptr = Vp + (size_t)(kok ? kp : 0) * a.v_rs + (size_t)h * a.v_hs + sd;
+            u32x4 kk[2], vv[2];                          // this thread's 16 dims of key row skey, packed bf16
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { kk[i] = *reinterpret_cast<const f32x4*>(kptr + 4 * i); vv[i] = *reinterpret_cast<const f32x4*>(vptr + 4 * i); }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { kk[i] = f32x4{0, 0, 0, 0}; vv[i] = f32x4{0, 0, 0, 0}; }
-            }
+            for (int i = 0; i < 2; ++i) { kk[i] = load8(kptr + 8 * i, kok); vv[i] = load8(vptr + 8 * i, kok); }
             __syncthreads();                             // previous tile fully consumed
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                u32x4 pk;
-                pk.x = (uint32_t)f2bf(kk[2 * i].x) | ((uint32_t)f2bf(kk[2 * i].y) << 16); pk.y = (uint32_t)f2bf(kk[2 * i].z) | ((uint32_t)f2bf(kk[2 * i].w) << 16);
-                pk.z = (uint32_t)f2bf(kk[2 * i + 1].x) | ((uint32_t)f2bf(kk[2 * i + 1].y) << 16); pk.w = (uint32_t)f2bf(kk[2 * i + 1].z) | ((uint32_t)f2bf(kk[2 * i + 1].w) << 16);
-                *reinterpret_cast<u32x4*>(&Ks[skey * AM_LD + sd + 8 * i]) = pk;
-            }
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Ks[skey * AM_LD + sd + 8 * i]) = kk[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Vt[(sd + 4 * i + 0) * AM_LD + skey] = f2bf(vv[i].x);
-                Vt[(sd + 4 * i + 1) * AM_LD + skey] = f2bf(vv[i].y);
-                Vt[(sd + 4 * i + 2) * AM_LD + skey] = f2bf(vv[i].z);
-                Vt[(sd + 4 * i + 3) * AM_LD + skey] = f2bf(vv[i].w);
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t wds[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vt[(sd + 8 * i + 2 * j + 0) * AM_LD + skey] = (bf16_t)(wds[j] & 0xffffu);
+                    Vt[(sd + 8 * i + 2 * j + 1) * AM_LD + skey] = (bf16_t)(wds[j] >> 16);
+                }
             }
             __syncthreads();
         }
@@ -283,17 +287,22 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
         const float l = row_sum16(lsum[r]);
         if (qrow < a.Sq) {
             const float inv = 1.0f / l;
-            float* op = a.O + (size_t)qrow * a.o_rs + h * 64 + m16;
+            IT* op = Op + (size_t)qrow * a.o_rs + h * 64 + m16;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) op[t * 16] = o[t][r] * inv;
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (sizeof(IT) == 4) op[t * 16] = o[t][r] * inv;
+                else op[t * 16] = f2bf(o[t][r] * inv);
+            }
         }
     }
 }
 
-// round_bf16 != 0 (bf16 policy): matrix cores; == 0 (fp32 "exact" policy): the exact-fp32 VALU kernel above
+// round_bf16 == 1 (bf16 policy): matrix cores, fp32 tensors (kernel-level entry point) | == 3: matrix cores, bf16 tensors (the
+// engine's bf16 policy) | == 0 (fp32 "exact" policy) and 2: the exact-fp32 VALU kernel above
 inline hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.Sq <= 0) return hipSuccess;
-    if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
+    if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel<float>, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
+    else if (a.round_bf16 == 3) hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -293,22 +293,4 @@ inline hipError_t launch_attn_decode(const float* q, const void* kc, const void*
     return hipGetLastError();
 }
 
-// fill the KV cache from prefill projections: src (B * rows, ld) fp32 with K at column koff + h*64 + d, V at voff + ...;
-// grid.y = batch row b: its `rows` source rows start at b * rows, its planes at b * kv_row_stride elements
-template <typename KT>
-__global__ void kv_fill_kernel(const float* __restrict__ src, int ld, int koff, int voff, int rows, int H, int max_seq,
-                               KT* __restrict__ kc, KT* __restrict__ vc, size_t kv_row_stride) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = rows * H * 64;
-    if (idx >= total) return;
-    const int b = blockIdx.y;
-    const int d = idx & 63, h = (idx >> 6) % H, r = idx / (64 * H);
-    const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
-    const float* sp = src + ((size_t)b * rows + r) * ld;
-    const float k = sp[koff + h * 64 + d];
-    const float v = sp[voff + h * 64 + d];
-    if constexpr (sizeof(KT) == 4) { kc[dst] = k; vc[dst] = v; }
-    else { kc[dst] = f2bf(k); vc[dst] = f2bf(v); }
-}
-
 }  // namespace ma

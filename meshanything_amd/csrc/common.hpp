@@ -147,6 +147,13 @@ __device__ inline u32x4 ld_stream16(const void* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 
+// logical row r of a batched tensor -> physical row: groups of `grp` rows sit `gstride` rows apart, shifted by `off`
+// (e.g. the 256 latent rows of sample b inside its 257-row block: grp 256, gstride 257, off 1).  grp == 0: identity.
+struct RowMap {
+    int grp, gstride, off;
+    __host__ __device__ inline size_t operator()(int r) const { return grp > 0 ? (size_t)(r / grp) * gstride + (r % grp) + off : (size_t)r; }
+};
+
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

@@ -1,0 +1,127 @@
+// Row-wise / gather kernels of the dense phases (point encoder, decoder prefill, detokenizer), for a BATCH of samples
+// stacked along the rows.  Two buffer kinds: fp32 "stream" tensors (residual streams, LayerNorm inputs, user-visible
+// outputs) and "activation" tensors of type AT that only ever feed a GEMM or the attention kernel -- AT = bf16_t under the
+// bf16 policy (the policy's rounding point at a GEMM / attention input is applied once, by the producer, and the tensor
+// crosses HBM in 2 bytes), AT = float under the fp32 "exact" policy.  Each kernel cites the reference lines it implements.
+#pragma once
+#include "common.hpp"
+#include "misc.hpp"
+
+namespace ma {
+
+template <typename T> __device__ __forceinline__ void st_act(T* p, float v);
+template <> __device__ __forceinline__ void st_act<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_act<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// FourierEmbedder.forward (embedder.py:87-105) + normals concat (sal_perceiver.py:87-89), rows = all points of the batch:
+// out[i] = [x(3) | sin(x_d * 2^f) (d-major) | cos(...) | normal(3) | 0-pad to ld]
+template <typename PT, typename AT>
+__global__ void fourier2_kernel(const PT* __restrict__ pc, int n_rows, int F, AT* __restrict__ out, int ld) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * ld) return;
+    const int i = idx / ld, col = idx - i * ld;
+    const PT* p = pc + (size_t)i * 6;
+    float v = 0.f;
+    if (col < 3) v = (float)p[col];
+    else if (col < 3 + 6 * F) {
+        const int j = (col - 3) % (3 * F);
+        const int dim = j / F, fr = j - dim * F;
+        const float arg = (float)p[dim] * (float)(1 << fr);
+        v = (col < 3 + 3 * F) ? sinf(arg) : cosf(arg);
+    } else if (col < 6 + 6 * F) v = (float)p[3 + col - (3 + 6 * F)];
+    st_act<AT>(out + idx, v);
+}
+
+// nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32): x fp32 -> y32 (fp32, optional) and
+// ya (AT, optional).  y32 may alias x.
+template <typename AT>
+__global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__ x, int ldx, RowMap xin, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps, float* y32, int ld32, AT* __restrict__ ya,
+                                                       int lda, RowMap yout, int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + xin(row) * ldx;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const size_t orow = yout(row);
+    for (int k = lane; k < D; k += 64) {
+        const float v = (xr[k] - mean) * rstd * g[k] + b[k];
+        if (y32) y32[orow * ld32 + k] = v;
+        if (ya) st_act<AT>(ya + orow * lda + k, v);
+    }
+}
+
+// out[i][n] = (mask == null || mask[i] ? in[i][n] : 0) + (t0 ? t0[n] : 0) + (tab ? tab[((tab_mod ? i % tab_mod : i) + row0) * ld_tab + n] : 0)
+// -> fp32 (out32, may alias in) and AT copy (outa, optional):
+//  - decoder prefill: prefix + cond_embed[0] + embed_positions[2 + i]         (shape_opt.py:331-337, 359-364)
+//  - detokenizer:     point feature + point_pe[i]; masked face embeds + pos_embedding[i]   (meshanything.py:47, 58-60)
+template <typename AT>
+__global__ void add_rows2_kernel(const float* in, int ld_in, const unsigned char* __restrict__ mask, const float* __restrict__ t0,
+                                 const float* __restrict__ tab, int ld_tab, int row0, float* out32, int ld_out, AT* __restrict__ outa,
+                                 int ld_outa, int rows, int cols, int tab_mod) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    float v = (mask == nullptr || mask[i]) ? in[(size_t)i * ld_in + n] : 0.f;
+    if (t0) v += t0[n];
+    if (tab) v += tab[(size_t)((tab_mod > 0 ? i % tab_mod : i) + row0) * ld_tab + n];
+    if (out32) out32[(size_t)i * ld_out + n] = v;
+    if (outa) st_act<AT>(outa + (size_t)i * ld_outa + n, v);
+}
+
+// dst[i][n] (AT) = mask == null || mask[i] ? src[in(i)][n] : 0   -- fp32 stream rows -> a GEMM operand (slices of the 257-row
+// latent blocks, the cat([latents, shape_latents]) of meshanything.py:128-131, the masked decoded faces of :66-68)
+template <typename AT>
+__global__ void cvt_rows_kernel(const float* __restrict__ src, int lds, RowMap in, const unsigned char* __restrict__ mask, AT* __restrict__ dst,
+                                int ldd, int rows, int cols) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const int i = idx / cols, n = idx - i * cols;
+    const float v = (mask == nullptr || mask[i]) ? src[in(i) * lds + n] : 0.f;
+    st_act<AT>(dst + (size_t)i * ldd + n, v);
+}
+
+// get_codes (meshanything.py:178-212) fused with the 'b (nf nv) d -> b nf (nv d)' rearrange (:53) and the face mask (:57), for
+// all faces of the batch: out[f][v*D + d] = sum_{q<3} codebook[ids[f*9 + v*3 + q]][d] (pad -1 contributes 0);
+// mask[f] = all nine ids != -1.  out32 (fp32, optional: ma_get_codes) and outa (AT, optional: the project_down GEMM operand).
+template <typename AT>
+__global__ void codes_gather2_kernel(const long long* __restrict__ ids, const float* __restrict__ codebook, int D, int nf, float* __restrict__ out32,
+                                     AT* __restrict__ outa, unsigned char* __restrict__ mask) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nf * 3 * D) return;
+    const int f = idx / (3 * D), rem = idx - f * 3 * D, v = rem / D, d = rem - v * D;
+    const long long* ip = ids + (size_t)f * 9 + v * 3;
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const long long id = ip[q]; c[q] = id < 0 ? 0.f : codebook[(size_t)id * D + d]; }
+    const float sum = (c[0] + c[1]) + c[2];
+    if (out32) out32[idx] = sum;
+    if (outa) st_act<AT>(outa + idx, sum);
+    if (rem == 0 && mask) {
+        bool ok = true;
+        for (int q = 0; q < 9; ++q) ok = ok && ids[(size_t)f * 9 + q] != -1;
+        mask[f] = ok ? 1 : 0;
+    }
+}
+
+// fill the KV cache from the prefill's fused q|k|v projection (AT): src (B * rows, ld) with K at column koff + h*64 + d, V at
+// voff + ...; grid.y = batch row b: its `rows` source rows start at b * rows, its planes at b * kv_row_stride elements
+template <typename AT, typename KT>
+__global__ void kv_fill2_kernel(const AT* __restrict__ src, int ld, int koff, int voff, int rows, int H, int max_seq, KT* __restrict__ kc,
+                                KT* __restrict__ vc, size_t kv_row_stride) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = rows * H * 64;
+    if (idx >= total) return;
+    const int b = blockIdx.y;
+    const int d = idx & 63, h = (idx >> 6) % H, r = idx / (64 * H);
+    const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
+    const AT* sp = src + ((size_t)b * rows + r) * ld;
+    if constexpr (sizeof(AT) == sizeof(KT)) { kc[dst] = sp[koff + h * 64 + d]; vc[dst] = sp[voff + h * 64 + d]; }     // same type: plain copy
+    else { kc[dst] = f2bf((float)sp[koff + h * 64 + d]); vc[dst] = f2bf((float)sp[voff + h * 64 + d]); }
+}
+
+}  // namespace ma

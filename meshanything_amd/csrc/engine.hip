@@ -22,6 +22,7 @@
 #include "attn.hpp"
 #include "attn_decode.hpp"
 #include "common.hpp"
+#include "dense_ops.hpp"
 #include "gemm.hpp"
 #include "gemm_decode.hpp"
 #include "gemm_tile.hpp"
@@ -83,13 +84,15 @@ struct ma_engine {
     std::map<int, hipGraphExec_t> gexec;
     hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the caller's may be the legacy null stream)
 
-    // dense-phase workspace (one sample at a time)
+    // dense-phase workspace: dense_rows samples stacked along the rows.  w_* / p_*: fp32 streams; a_*: activation tensors
+    // (dense_ops.hpp: act_elem = 2 bytes under the bf16 policy, 4 under the exact policy)
     std::vector<void*> allocs;
-    float *w_feat = nullptr, *w_data = nullptr, *w_dataln = nullptr, *w_kv = nullptr, *w_a = nullptr, *w_b = nullptr, *w_c = nullptr,
-          *w_qkv = nullptr, *w_mlp = nullptr, *w_lat = nullptr, *w_cat = nullptr, *w_mean = nullptr;
-    float *w_x = nullptr, *w_fein = nullptr, *w_fe = nullptr, *w_logit = nullptr;
-    float *p_h = nullptr, *p_qkv = nullptr, *p_att = nullptr, *p_y = nullptr, *p_ffn = nullptr;    // prefill workspace: prefill_rows samples stacked
-    int prefill_rows = 1;
+    size_t act_elem = 2;
+    int dense_rows = 1, prefill_rows = 1;
+    float *w_data = nullptr, *w_lat = nullptr, *w_lat2 = nullptr, *w_pf = nullptr, *w_x = nullptr, *w_y = nullptr, *w_fe = nullptr, *w_logit = nullptr;
+    float *p_h = nullptr, *p_y = nullptr;
+    void *a_feat = nullptr, *a_dataln = nullptr, *a_kv = nullptr, *a_q = nullptr, *a_ln = nullptr, *a_qkv = nullptr, *a_att = nullptr, *a_mlp = nullptr,
+         *a_cat = nullptr, *a_mean = nullptr, *a_fein = nullptr, *a_x = nullptr, *a_ph = nullptr, *a_pqkv = nullptr, *a_patt = nullptr, *a_pffn = nullptr;
     unsigned char* w_mask = nullptr;
     float *w_latents = nullptr, *w_prefix = nullptr, *w_coords = nullptr;   // ma_forward intermediates (max_batch rows)
     long long *w_tokens = nullptr, *w_ids = nullptr;
@@ -131,101 +134,147 @@ namespace {
 
 const std::string SM = "point_encoder.model.shape_model.", DEC = "transformer.model.decoder.", TOK = "tokenizer.";
 
-// ------------------------------------------------------------------------------------------------ launch helpers
-void gemm(ma_engine* e, hipStream_t s, const float* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr,
-          float* C, int ldc, int M, int act, int n_override = 0) {
+// ------------------------------------------------------------------------------------------------ dense-phase helpers
+// Buffer kinds (dense_ops.hpp): fp32 "stream" tensors (float*) and "activation" tensors (void*, element = e->act_elem bytes:
+// bf16 under the bf16 policy, fp32 under the exact policy).  All dense phases run a CHUNK of nb <= e->dense_rows samples at
+// once, stacked along the GEMM rows.
+inline void* aoff(ma_engine* e, void* p, size_t elems) { return reinterpret_cast<char*>(p) + elems * e->act_elem; }
+inline const void* aoff(ma_engine* e, const void* p, size_t elems) { return reinterpret_cast<const char*>(p) + elems * e->act_elem; }
+
+struct GemmOut {                       // exactly one of: fp32 stream output | activation output
+    float* c32 = nullptr; void* act = nullptr; int ld = 0; RowMap map{0, 0, 0};
+};
+// C = act(A . W^T + bias) + R, A an activation tensor (M, lda).  r_mod > 0: the residual row is m % r_mod.
+void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr, GemmOut out,
+          int M, int act, int r_mod = 0) {
     const Entry& en = e->L.get(w);
-    GemmArgs g{A, lda, e->arena + en.offset, bias_name ? e->PF(bias_name) : nullptr, R, ldr, C, ldc, M, n_override ? n_override : en.rows, en.cols, act};
-    hipError_t r = e->bf16 ? launch_gemm<bf16_t>(g, e->opt_gemm_impl, s) : launch_gemm<float>(g, e->opt_gemm_impl, s);
+    const float* bias = bias_name ? e->PF(bias_name) : nullptr;
+    hipError_t r;
+    if (e->bf16) {
+        GemmTArgs t{};
+        t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
+        t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
+        t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map;
+        r = launch_gemm_tile(t, s);
+    } else {
+        GemmArgs g{};
+        g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
+        g.C = out.c32 ? out.c32 : reinterpret_cast<float*>(out.act); g.ldc = out.ld; g.M = M; g.N = en.rows; g.K = en.cols; g.act = act;
+        g.r_mod = r_mod; g.cmap = out.map;
+        r = launch_gemm<float>(g, e->opt_gemm_impl, s);
+    }
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, "gemm launch failed for " + w + ": " + hipGetErrorString(r));
 }
-void gemm(ma_engine* e, hipStream_t s, const float* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr,
-          float* C, int ldc, int M, int act) {
-    gemm(e, s, A, lda, w, b.c_str(), R, ldr, C, ldc, M, act);
+void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr, GemmOut out, int M,
+          int act, int r_mod = 0) {
+    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod);
 }
-void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y, int ldy, int rows, int D,
-            const char* wkey = "weight", const char* bkey = "bias") {
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, e->PF(prefix + wkey), e->PF(prefix + bkey), eps, y, ldy, rows, D);
+GemmOut to32(float* c, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.c32 = c; o.ld = ld; o.map = m; return o; }
+GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = a; o.ld = ld; o.map = m; return o; }
+
+// LayerNorm rows: x fp32 (row map xin) -> y32 (fp32, optional) and ya (activation, optional), both at row map yout
+void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y32, int ld32, void* ya, int lda, int rows,
+            int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}) {
+    const float* g = e->PF(prefix + "weight"); const float* b = e->PF(prefix + "bias");
+    if (e->bf16) hipLaunchKernelGGL((ln_rows2_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<bf16_t*>(ya), lda, yout, rows, D);
+    else hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D);
     HIP_CHECK(hipGetLastError());
 }
-void attention(ma_engine* e, hipStream_t s, const float* Q, int q_rs, int q_hs, const float* K, int k_rs, int k_hs, const float* Vp, int v_rs,
-               int v_hs, float* O, int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0,
-               size_t o_bs = 0) {
-    AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 1 : 0};
+// attention over activation tensors; strides in elements; batch = samples (grid.z)
+void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, const void* K, int k_rs, int k_hs, const void* Vp, int v_rs, int v_hs, void* O,
+               int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0) {
+    AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 3 : 0};
     a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     HIP_CHECK(launch_attention(a, s));
 }
-void copy2d(hipStream_t s, const float* src, int lds, float* dst, int ldd, int rows, int cols) {
-    hipLaunchKernelGGL(copy2d_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+// fp32 stream rows (row map in, optional row mask) -> activation tensor
+void cvt_rows(ma_engine* e, hipStream_t s, const float* src, int lds, RowMap in, const unsigned char* mask, void* dst, int ldd, int rows, int cols) {
+    if (e->bf16) hipLaunchKernelGGL((cvt_rows_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<bf16_t*>(dst), ldd, rows, cols);
+    else hipLaunchKernelGGL((cvt_rows_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<float*>(dst), ldd, rows, cols);
     HIP_CHECK(hipGetLastError());
 }
-void add_rows(hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
-              float* out, int ld_out, int rows, int cols, int tab_mod = 0) {
-    hipLaunchKernelGGL(add_rows_kernel, dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out, ld_out, rows, cols, tab_mod);
+void add_rows(ma_engine* e, hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
+              float* out32, int ld_out, void* outa, int ld_outa, int rows, int cols, int tab_mod = 0) {
+    if (e->bf16) hipLaunchKernelGGL((add_rows2_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
+                                    reinterpret_cast<bf16_t*>(outa), ld_outa, rows, cols, tab_mod);
+    else hipLaunchKernelGGL((add_rows2_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
+                            reinterpret_cast<float*>(outa), ld_outa, rows, cols, tab_mod);
     HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------ point encoder
-// ResidualAttentionBlock (transformer_blocks.py:109-112): x += proj(attn(c_qkv(ln_1 x))); x += mlp(ln_2 x).  x: (rows, W) in place.
-void miche_block(ma_engine* e, hipStream_t s, float* x, int rows, const std::string& p) {
-    const int W = e->cfg.enc_width, Hh = e->cfg.enc_heads;
-    lnrows(e, s, x, W, p + "ln_1.", 1e-5f, e->w_a, W, rows, W);
-    gemm(e, s, e->w_a, W, p + "attn.c_qkv.weight", nullptr, nullptr, 0, e->w_qkv, 3 * W, rows, ACT_NONE);
+// ResidualAttentionBlock (transformer_blocks.py:109-112): x += proj(attn(c_qkv(ln_1 x))); x += mlp(ln_2 x), for nb samples of S
+// rows each stacked in x (nb * S, W) fp32, in place.
+void miche_block(ma_engine* e, hipStream_t s, float* x, int S, int nb, const std::string& p) {
+    const int W = e->cfg.enc_width, Hh = e->cfg.enc_heads, rows = nb * S;
+    lnrows(e, s, x, W, p + "ln_1.", 1e-5f, nullptr, 0, e->a_ln, W, rows, W);
+    gemm(e, s, e->a_ln, W, p + "attn.c_qkv.weight", nullptr, nullptr, 0, toact(e->a_qkv, 3 * W), rows, ACT_NONE);
     // per-head interleaved [q|k|v] (transformer_blocks.py:61-62): head stride 192, k at +64, v at +128
-    attention(e, s, e->w_qkv, 3 * W, 192, e->w_qkv + 64, 3 * W, 192, e->w_qkv + 128, 3 * W, 192, e->w_b, W, rows, rows, Hh, -1);
-    gemm(e, s, e->w_b, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", x, W, x, W, rows, ACT_NONE);
-    lnrows(e, s, x, W, p + "ln_2.", 1e-5f, e->w_a, W, rows, W);
-    gemm(e, s, e->w_a, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, e->w_mlp, 4 * W, rows, ACT_GELU);
-    gemm(e, s, e->w_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", x, W, x, W, rows, ACT_NONE);
+    attention(e, s, e->a_qkv, 3 * W, 192, aoff(e, e->a_qkv, 64), 3 * W, 192, aoff(e, e->a_qkv, 128), 3 * W, 192, e->a_att, W, S, S, Hh, -1, nb, (size_t)S * 3 * W,
+              (size_t)S * 3 * W, (size_t)S * 3 * W, (size_t)S * W);
+    gemm(e, s, e->a_att, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", x, W, to32(x, W), rows, ACT_NONE);
+    lnrows(e, s, x, W, p + "ln_2.", 1e-5f, nullptr, 0, e->a_ln, W, rows, W);
+    gemm(e, s, e->a_ln, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, toact(e->a_mlp, 4 * W), rows, ACT_GELU);
+    gemm(e, s, e->a_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", x, W, to32(x, W), rows, ACT_NONE);
 }
 
-// encode_latents (asl_pl_module.py:145-157 -> sal_perceiver.py:372-381 -> 74-99) for ONE sample -> latents (T, W)
-void encode_one(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, float* latents) {
+// encode_latents (asl_pl_module.py:145-157 -> sal_perceiver.py:372-381 -> 74-99) for nb samples -> latents (nb, T, W) fp32
+void encode_chunk(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, int nb, float* latents) {
     const ma_config& c = e->cfg;
-    const int N = c.n_points, W = c.enc_width, T = e->T, Hh = c.enc_heads;
-    if (pc_dtype == MA_DTYPE_F16)
-        hipLaunchKernelGGL((fourier_kernel<_Float16>), dim3(ceil_div(N * 64, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), N, c.num_freqs, e->w_feat, 64);
-    else
-        hipLaunchKernelGGL((fourier_kernel<float>), dim3(ceil_div(N * 64, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), N, c.num_freqs, e->w_feat, 64);
-    HIP_CHECK(hipGetLastError());
-    gemm(e, s, e->w_feat, 64, SM + "encoder.input_proj.weight", SM + "encoder.input_proj.bias", nullptr, 0, e->w_data, W, N, ACT_NONE);
+    const int N = c.n_points, W = c.enc_width, T = e->T, Hh = c.enc_heads, rowsN = nb * N, rowsT = nb * T;
+    {
+        const int total = rowsN * 64;
+        if (pc_dtype == MA_DTYPE_F16) {
+            if (e->bf16) hipLaunchKernelGGL((fourier2_kernel<_Float16, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            else hipLaunchKernelGGL((fourier2_kernel<_Float16, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
+        } else {
+            if (e->bf16) hipLaunchKernelGGL((fourier2_kernel<float, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            else hipLaunchKernelGGL((fourier2_kernel<float, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
+        }
+        HIP_CHECK(hipGetLastError());
+    }
+    gemm(e, s, e->a_feat, 64, SM + "encoder.input_proj.weight", SM + "encoder.input_proj.bias", nullptr, 0, to32(e->w_data, W), rowsN, ACT_NONE);
     const std::string p = SM + "encoder.cross_attn.";
     const float* query = e->PF(SM + "encoder.query");
-    // x = query + attn(ln_1 query, ln_2 data); x += mlp(ln_3 x)     (transformer_blocks.py:223-226)
-    lnrows(e, s, query, W, p + "ln_1.", 1e-5f, e->w_a, W, T, W);
-    gemm(e, s, e->w_a, W, p + "attn.c_q.weight", nullptr, nullptr, 0, e->w_b, W, T, ACT_NONE);
-    lnrows(e, s, e->w_data, W, p + "ln_2.", 1e-5f, e->w_dataln, W, N, W);
-    gemm(e, s, e->w_dataln, W, p + "attn.c_kv.weight", nullptr, nullptr, 0, e->w_kv, 2 * W, N, ACT_NONE);
+    // x = query + attn(ln_1 query, ln_2 data); x += mlp(ln_3 x)     (transformer_blocks.py:223-226).  The query side is the same
+    // for every sample: computed once, attended by every sample's keys (q batch stride 0)
+    lnrows(e, s, query, W, p + "ln_1.", 1e-5f, nullptr, 0, e->a_ln, W, T, W);
+    gemm(e, s, e->a_ln, W, p + "attn.c_q.weight", nullptr, nullptr, 0, toact(e->a_q, W), T, ACT_NONE);
+    lnrows(e, s, e->w_data, W, p + "ln_2.", 1e-5f, nullptr, 0, e->a_dataln, W, rowsN, W);
+    gemm(e, s, e->a_dataln, W, p + "attn.c_kv.weight", nullptr, nullptr, 0, toact(e->a_kv, 2 * W), rowsN, ACT_NONE);
     // kv viewed (N, heads, 128) split [k|v] (transformer_blocks.py:172-174)
-    attention(e, s, e->w_b, W, 64, e->w_kv, 2 * W, 128, e->w_kv + 64, 2 * W, 128, e->w_c, W, T, N, Hh, -1);
-    gemm(e, s, e->w_c, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", query, W, e->w_lat, W, T, ACT_NONE);
-    lnrows(e, s, e->w_lat, W, p + "ln_3.", 1e-5f, e->w_a, W, T, W);
-    gemm(e, s, e->w_a, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, e->w_mlp, 4 * W, T, ACT_GELU);
-    gemm(e, s, e->w_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", e->w_lat, W, e->w_lat, W, T, ACT_NONE);
-    for (int n = 0; n < c.enc_layers; ++n) miche_block(e, s, e->w_lat, T, SM + "encoder.self_attn.resblocks." + std::to_string(n) + ".");
-    lnrows(e, s, e->w_lat, W, SM + "encoder.ln_post.", 1e-5f, latents, W, T, W);
+    attention(e, s, e->a_q, W, 64, e->a_kv, 2 * W, 128, aoff(e, e->a_kv, 64), 2 * W, 128, e->a_att, W, T, N, Hh, -1, nb, 0, (size_t)N * 2 * W, (size_t)N * 2 * W,
+              (size_t)T * W);
+    gemm(e, s, e->a_att, W, p + "attn.c_proj.weight", p + "attn.c_proj.bias", query, W, to32(e->w_lat, W), rowsT, ACT_NONE, /*r_mod=*/T);
+    lnrows(e, s, e->w_lat, W, p + "ln_3.", 1e-5f, nullptr, 0, e->a_ln, W, rowsT, W);
+    gemm(e, s, e->a_ln, W, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", nullptr, 0, toact(e->a_mlp, 4 * W), rowsT, ACT_GELU);
+    gemm(e, s, e->a_mlp, 4 * W, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", e->w_lat, W, to32(e->w_lat, W), rowsT, ACT_NONE);
+    for (int n = 0; n < c.enc_layers; ++n) miche_block(e, s, e->w_lat, T, nb, SM + "encoder.self_attn.resblocks." + std::to_string(n) + ".");
+    lnrows(e, s, e->w_lat, W, SM + "encoder.ln_post.", 1e-5f, latents, W, nullptr, 0, rowsT, W);
 }
 
-// to_shape_latents (asl_pl_module.py:182-185 -> sal_perceiver.py:383-396 pre_kl / mode() / post_kl, 273-275 transformer)
-// for ONE sample: lat (NL, ld) -> e->w_lat (NL, W)
-void shape_latents_one(ma_engine* e, hipStream_t s, const float* lat, int ld) {
+// to_shape_latents (asl_pl_module.py:182-185 -> sal_perceiver.py:383-396 pre_kl / mode() / post_kl, 273-275 transformer) for nb
+// samples: lat rows `in` of a (.., ld) fp32 tensor -> e->w_lat2 (nb * NL, W) fp32
+void shape_latents_chunk(ma_engine* e, hipStream_t s, const float* lat, int ld, RowMap in, int nb) {
     const ma_config& c = e->cfg;
-    const int W = c.enc_width, E = c.embed_dim, NL = c.num_latents;
-    gemm(e, s, lat, ld, SM + "pre_kl.weight", SM + "pre_kl.bias", nullptr, 0, e->w_mean, E, NL, ACT_NONE);      // posterior.mode(): the mean half
-    gemm(e, s, e->w_mean, E, SM + "post_kl.weight", SM + "post_kl.bias", nullptr, 0, e->w_lat, W, NL, ACT_NONE);
-    for (int n = 0; n < c.shape_layers; ++n) miche_block(e, s, e->w_lat, NL, SM + "transformer.resblocks." + std::to_string(n) + ".");
+    const int W = c.enc_width, E = c.embed_dim, NL = c.num_latents, rows = nb * NL;
+    cvt_rows(e, s, lat, ld, in, nullptr, e->a_ln, W, rows, W);
+    gemm(e, s, e->a_ln, W, SM + "pre_kl.weight", SM + "pre_kl.bias", nullptr, 0, toact(e->a_mean, E), rows, ACT_NONE);      // posterior.mode(): the mean half
+    gemm(e, s, e->a_mean, E, SM + "post_kl.weight", SM + "post_kl.bias", nullptr, 0, to32(e->w_lat2, W), rows, ACT_NONE);
+    for (int n = 0; n < c.shape_layers; ++n) miche_block(e, s, e->w_lat2, NL, nb, SM + "transformer.resblocks." + std::to_string(n) + ".");
 }
 
-// process_point_feature (meshanything.py:125-132) incl. to_shape_latents for ONE sample
-void prefix_one(ma_engine* e, hipStream_t s, const float* latents, float* prefix) {
+// process_point_feature (meshanything.py:125-132) incl. to_shape_latents for nb samples: latents (nb, T, W) -> prefix (nb, T, H)
+void prefix_chunk(ma_engine* e, hipStream_t s, const float* latents, float* prefix, int nb) {
     const ma_config& c = e->cfg;
-    const int W = c.enc_width, H = c.hidden, NL = c.num_latents;
-    const float* lat1 = latents + W;                                       // point_feature[:, 1:]
-    shape_latents_one(e, s, lat1, W);
-    copy2d(s, lat1, W, e->w_cat, 2 * W, NL, W);                            // cat([latents, shape_latents], -1)
-    copy2d(s, e->w_lat, W, e->w_cat + W, 2 * W, NL, W);
-    gemm(e, s, latents, W, "cond_head_proj.weight", "cond_head_proj.bias", nullptr, 0, prefix, H, 1, ACT_NONE);
-    gemm(e, s, e->w_cat, 2 * W, "cond_proj.weight", "cond_proj.bias", nullptr, 0, prefix + H, H, NL, ACT_NONE);
+    const int W = c.enc_width, H = c.hidden, NL = c.num_latents, T = e->T, rows = nb * NL;
+    const RowMap tail{NL, T, 1}, head{1, T, 0};                            // point_feature[:, 1:] and [:, 0] inside the T-row blocks
+    shape_latents_chunk(e, s, latents, W, tail, nb);
+    cvt_rows(e, s, latents, W, tail, nullptr, e->a_cat, 2 * W, rows, W);                            // cat([latents, shape_latents], -1)
+    cvt_rows(e, s, e->w_lat2, W, RowMap{0, 0, 0}, nullptr, aoff(e, e->a_cat, W), 2 * W, rows, W);
+    cvt_rows(e, s, latents, W, head, nullptr, e->a_ln, W, nb, W);
+    gemm(e, s, e->a_ln, W, "cond_head_proj.weight", "cond_head_proj.bias", nullptr, 0, to32(prefix, H, head), nb, ACT_NONE);
+    gemm(e, s, e->a_cat, 2 * W, "cond_proj.weight", "cond_proj.bias", nullptr, 0, to32(prefix, H, tail), rows, ACT_NONE);
 }
 
 // ------------------------------------------------------------------------------------------------ decoder
@@ -550,7 +599,7 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
     const int T = e->T, H = c.hidden, M = B * T;
     StepTimer none;
     float* h = e->p_h;                       // (B*T, H)
-    add_rows(s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, M, H, T);
+    add_rows(e, s, prefix, H, nullptr, e->PF(DEC + "cond_embed.weight"), e->PF(DEC + "embed_positions.weight"), H, 2, h, H, e->a_ph, H, M, H, T);
     if (e->opt_prefill_stepwise) {
         // debug path: feed the prefix rows through the decode-step kernels one position at a time, one sample at a time
         for (int b = 0; b < B; ++b) {
@@ -567,27 +616,28 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
         }
         return;
     }
-    float* qkv = e->p_qkv;                   // (B*T, 3H)
-    float* att = e->p_att;                   // (B*T, H)
+    void* qkv = e->a_pqkv;                   // (B*T, 3H) activation
+    void* att = e->a_patt;                   // (B*T, H) activation
+    void* hb = e->a_ph;                      // (B*T, H) activation copy of h
     float* y = e->p_y;                       // (B*T, H)
-    float* ffn = e->p_ffn;                   // (B*T, ffn)
+    void* ffn = e->a_pffn;                   // (B*T, ffn) activation
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = DEC + "layers." + std::to_string(l) + ".";
-        gemm(e, s, h, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * H, M, ACT_NONE);
+        gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE);
         const int n = T * c.heads * 64;
-        if (e->bf16) hipLaunchKernelGGL((kv_fill_kernel<bf16_t>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                        reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);
-        else hipLaunchKernelGGL((kv_fill_kernel<float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, qkv, 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+        if (e->bf16) hipLaunchKernelGGL((kv_fill2_kernel<bf16_t, bf16_t>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, T, c.heads,
+                                        e->maxseq, reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);
+        else hipLaunchKernelGGL((kv_fill2_kernel<float, float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const float*>(qkv), 3 * H, H, 2 * H, T, c.heads, e->maxseq,
                                 reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
         HIP_CHECK(hipGetLastError());
-        attention(e, s, qkv, 3 * H, 64, qkv + H, 3 * H, 64, qkv + 2 * H, 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
+        attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
                   (size_t)T * 3 * H, (size_t)T * H);
-        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, y, H, M, ACT_NONE);
-        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, M, H);
-        gemm(e, s, h, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, ffn, c.ffn, M, ACT_RELU);
-        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, y, H, M, ACT_NONE);
-        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, M, H);
+        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, to32(y, H), M, ACT_NONE);
+        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, hb, H, M, H);
+        gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU);
+        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, to32(y, H), M, ACT_NONE);
+        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, hb, H, M, H);
     }
     // only the last prefix row of every sample feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
     enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, T * H, nullptr, nullptr, none, Rows{row0, B});
@@ -668,38 +718,54 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
 }
 
 // ------------------------------------------------------------------------------------------------ detokenizer
-void detok_one(ma_engine* e, hipStream_t s, const long long* ids, const float* latents, float* coords) {
+// NoiseResistantDecoder.forward (meshanything.py:50-80) for nb samples stacked along the rows: X (nb, S = T + nf, Wt).
+// codes != null: the caller's `input_embeds` (B, 3 nf, D) fp32 are used as the face codes (what the reference's signature
+// takes); null: they are gathered from the codebook (get_codes, meshanything.py:178-212) inside the chain.
+void detok_chunk(ma_engine* e, hipStream_t s, const long long* ids, const float* codes, const float* latents, float* coords, int nb) {
     const ma_config& c = e->cfg;
     const int W = c.enc_width, T = e->T, Wt = c.tok_width, nf = e->nf, S = e->S, D = c.codebook_dim, Hh = c.tok_heads;
-    float* X = e->w_x;                                               // (S, Wt)
-    // process_point_feature (meshanything.py:42-48)
-    gemm(e, s, latents, W, TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias", nullptr, 0, e->w_a, Wt, 1, ACT_NONE);
-    gemm(e, s, latents + W, W, TOK + "cond_proj.weight", TOK + "cond_proj.bias", nullptr, 0, e->w_a + Wt, Wt, T - 1, ACT_NONE);
-    add_rows(s, e->w_a, Wt, nullptr, nullptr, e->PF(TOK + "point_pe.weight"), Wt, 0, e->w_a, Wt, T, Wt);
-    lnrows(e, s, e->w_a, Wt, TOK + "point_layernorm.", 1e-5f, X, Wt, T, Wt);
+    const int rowsS = nb * S, rowsF = nb * nf;
+    float* X = e->w_x;                                               // (nb * S, Wt) fp32
+    void* Xb = e->a_x;                                               // activation copy
+    const RowMap head_in{1, T, 0}, tail_in{T - 1, T, 1};             // latents[:, 0] / [:, 1:] inside the T-row blocks
+    const RowMap cond_out{T, S, 0}, face_out{nf, S, T};              // cond rows / face rows inside the S-row blocks of X
+    // process_point_feature (meshanything.py:42-48): -> w_pf (nb * T, Wt)
+    cvt_rows(e, s, latents, W, head_in, nullptr, e->a_ln, W, nb, W);
+    gemm(e, s, e->a_ln, W, TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{1, T, 0}), nb, ACT_NONE);
+    cvt_rows(e, s, latents, W, tail_in, nullptr, e->a_ln, W, nb * (T - 1), W);
+    gemm(e, s, e->a_ln, W, TOK + "cond_proj.weight", TOK + "cond_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{T - 1, T, 1}), nb * (T - 1), ACT_NONE);
+    add_rows(e, s, e->w_pf, Wt, nullptr, nullptr, e->PF(TOK + "point_pe.weight"), Wt, 0, e->w_pf, Wt, nullptr, 0, nb * T, Wt, T);
+    lnrows(e, s, e->w_pf, Wt, TOK + "point_layernorm.", 1e-5f, X, Wt, Xb, Wt, nb * T, Wt, RowMap{0, 0, 0}, cond_out);
     // faces (meshanything.py:53-60): codes -> project_down -> zero masked -> + pos -> LN
-    hipLaunchKernelGGL(codes_gather_kernel, dim3(ceil_div(nf * 3 * D, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, nf, e->w_fein, e->w_mask);
-    HIP_CHECK(hipGetLastError());
-    gemm(e, s, e->w_fein, 3 * D, TOK + "project_down_codebook.weight", TOK + "project_down_codebook.bias", nullptr, 0, e->w_fe, Wt, nf, ACT_NONE);
-    add_rows(s, e->w_fe, Wt, e->w_mask, nullptr, e->PF(TOK + "pos_embedding.weight"), Wt, 0, e->w_fe, Wt, nf, Wt);
-    lnrows(e, s, e->w_fe, Wt, TOK + "layernorm.", 1e-5f, X + (size_t)T * Wt, Wt, nf, Wt);
+    {
+        const int total = rowsF * 3 * D;
+        if (e->bf16) hipLaunchKernelGGL((codes_gather2_kernel<bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
+                                        codes ? nullptr : reinterpret_cast<bf16_t*>(e->a_fein), e->w_mask);
+        else hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
+                                codes ? nullptr : reinterpret_cast<float*>(e->a_fein), e->w_mask);
+        HIP_CHECK(hipGetLastError());
+        if (codes) cvt_rows(e, s, codes, 3 * D, RowMap{0, 0, 0}, nullptr, e->a_fein, 3 * D, rowsF, 3 * D);     // 'b (nf nv) d -> b nf (nv d)' is a view
+    }
+    gemm(e, s, e->a_fein, 3 * D, TOK + "project_down_codebook.weight", TOK + "project_down_codebook.bias", nullptr, 0, to32(e->w_fe, Wt), rowsF, ACT_NONE);
+    add_rows(e, s, e->w_fe, Wt, e->w_mask, nullptr, e->PF(TOK + "pos_embedding.weight"), Wt, 0, e->w_fe, Wt, nullptr, 0, rowsF, Wt, nf);
+    lnrows(e, s, e->w_fe, Wt, TOK + "layernorm.", 1e-5f, X, Wt, Xb, Wt, rowsF, Wt, RowMap{0, 0, 0}, face_out);
     // 6 BERT post-LN layers, bidirectional, NO mask: padding faces take part as LN(pos_embedding[i]) tokens
-    float* qkv = e->w_qkv; float* att = e->w_b; float* y = e->w_c; float* ffn = e->w_mlp;
+    void* qkv = e->a_qkv; void* att = e->a_att; float* y = e->w_y; void* ffn = e->a_mlp;
     for (int n = 0; n < c.tok_layers; ++n) {
         const std::string p = TOK + "decoder.layer." + std::to_string(n) + ".";
-        gemm(e, s, X, Wt, p + "qkv.weight", p + "qkv.bias", nullptr, 0, qkv, 3 * Wt, S, ACT_NONE);
-        attention(e, s, qkv, 3 * Wt, 64, qkv + Wt, 3 * Wt, 64, qkv + 2 * Wt, 3 * Wt, 64, att, Wt, S, S, Hh, -1);
-        gemm(e, s, att, Wt, p + "attention.output.dense.weight", p + "attention.output.dense.bias", X, Wt, y, Wt, S, ACT_NONE);
-        lnrows(e, s, y, Wt, p + "attention.output.LayerNorm.", 1e-12f, X, Wt, S, Wt);
-        gemm(e, s, X, Wt, p + "intermediate.dense.weight", p + "intermediate.dense.bias", nullptr, 0, ffn, c.tok_ffn, S, ACT_GELU);
-        gemm(e, s, ffn, c.tok_ffn, p + "output.dense.weight", p + "output.dense.bias", X, Wt, y, Wt, S, ACT_NONE);
-        lnrows(e, s, y, Wt, p + "output.LayerNorm.", 1e-12f, X, Wt, S, Wt);
+        gemm(e, s, Xb, Wt, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * Wt), rowsS, ACT_NONE);
+        attention(e, s, qkv, 3 * Wt, 64, aoff(e, qkv, Wt), 3 * Wt, 64, aoff(e, qkv, 2 * Wt), 3 * Wt, 64, att, Wt, S, S, Hh, -1, nb, (size_t)S * 3 * Wt, (size_t)S * 3 * Wt,
+                  (size_t)S * 3 * Wt, (size_t)S * Wt);
+        gemm(e, s, att, Wt, p + "attention.output.dense.weight", p + "attention.output.dense.bias", X, Wt, to32(y, Wt), rowsS, ACT_NONE);
+        lnrows(e, s, y, Wt, p + "attention.output.LayerNorm.", 1e-12f, X, Wt, Xb, Wt, rowsS, Wt);
+        gemm(e, s, Xb, Wt, p + "intermediate.dense.weight", p + "intermediate.dense.bias", nullptr, 0, toact(ffn, c.tok_ffn), rowsS, ACT_GELU);
+        gemm(e, s, ffn, c.tok_ffn, p + "output.dense.weight", p + "output.dense.bias", X, Wt, to32(y, Wt), rowsS, ACT_NONE);
+        lnrows(e, s, y, Wt, p + "output.LayerNorm.", 1e-12f, X, Wt, Xb, Wt, rowsS, Wt);
     }
-    float* decoded = X + (size_t)T * Wt;                              // last_hidden_state[:, cond_length:]
-    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3(ceil_div(nf * Wt, 256)), dim3(256), 0, s, decoded, Wt, e->w_mask, nf, Wt);
-    HIP_CHECK(hipGetLastError());
-    gemm(e, s, decoded, Wt, TOK + "to_coor_logits.0.weight", TOK + "to_coor_logits.0.bias", nullptr, 0, e->w_logit, 9 * c.discrete_num, nf, ACT_NONE);
-    hipLaunchKernelGGL(coords_argmax_kernel, dim3(ceil_div(nf * 9, 4)), dim3(256), 0, s, e->w_logit, nf, c.discrete_num, e->w_mask, coords);
+    // last_hidden_state[:, cond_length:], masked faces zeroed (meshanything.py:65-68) -> to_coor_logits
+    cvt_rows(e, s, X, Wt, face_out, e->w_mask, e->a_ln, Wt, rowsF, Wt);
+    gemm(e, s, e->a_ln, Wt, TOK + "to_coor_logits.0.weight", TOK + "to_coor_logits.0.bias", nullptr, 0, to32(e->w_logit, 9 * c.discrete_num), rowsF, ACT_NONE);
+    hipLaunchKernelGGL(coords_argmax_kernel, dim3(ceil_div(rowsF * 9, 4)), dim3(256), 0, s, e->w_logit, rowsF, c.discrete_num, e->w_mask, coords);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -774,24 +840,30 @@ void build_engine(ma_engine* e) {
     }
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));
-    // dense workspace, one sample
-    const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S;
-    const size_t rows_small = std::max(T, S);                       // rows of the latent / token streams
-    const size_t wmax = std::max(std::max(W, H), Wt);
-    const size_t fmax = std::max(std::max(4 * W, c.ffn), c.tok_ffn);
-    e->w_feat = e->dmalloc<float>((size_t)N * 64);
-    e->w_data = e->dmalloc<float>((size_t)N * W); e->w_dataln = e->dmalloc<float>((size_t)N * W); e->w_kv = e->dmalloc<float>((size_t)N * 2 * W);
-    e->w_a = e->dmalloc<float>(rows_small * wmax); e->w_b = e->dmalloc<float>(rows_small * wmax); e->w_c = e->dmalloc<float>(rows_small * wmax);
-    e->w_x = e->dmalloc<float>(rows_small * wmax);
-    e->w_qkv = e->dmalloc<float>(rows_small * 3 * wmax); e->w_mlp = e->dmalloc<float>(rows_small * fmax);
-    e->w_lat = e->dmalloc<float>((size_t)T * W); e->w_cat = e->dmalloc<float>((size_t)T * 2 * W); e->w_mean = e->dmalloc<float>((size_t)T * c.embed_dim);
-    e->w_fein = e->dmalloc<float>((size_t)e->nf * 3 * c.codebook_dim); e->w_fe = e->dmalloc<float>((size_t)e->nf * Wt);
-    e->w_logit = e->dmalloc<float>((size_t)e->nf * 9 * c.discrete_num); e->w_mask = e->dmalloc<unsigned char>(e->nf);
-    e->prefill_rows = std::min(c.max_batch, 16);                     // 16 x 257 rows per pass: 4112-row GEMMs, ~170 MB of workspace
+    // dense workspace: R = dense_rows samples stacked along the rows (16 x 4096 point rows / 16 x 257 latent rows / 16 x 1057
+    // detokenizer rows per pass: ~1.3 GB at the 350M shape under the bf16 policy)
+    const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S, NL = c.num_latents;
+    e->act_elem = e->bf16 ? 2 : 4;
+    e->dense_rows = std::min(c.max_batch, 16);
+    e->prefill_rows = e->dense_rows;
+    const size_t R = e->dense_rows;
+    const size_t rows_seq = R * std::max(T, S);                      // rows of the latent / token streams
+    const size_t wmax = std::max(W, Wt);
+    const size_t fmax = std::max(4 * W, c.tok_ffn);
+    auto amalloc = [&](size_t elems) -> void* { return e->dmalloc<char>(elems * e->act_elem); };
+    e->w_data = e->dmalloc<float>(R * N * W);
+    e->w_lat = e->dmalloc<float>(R * T * W); e->w_lat2 = e->dmalloc<float>(R * NL * W);
+    e->w_pf = e->dmalloc<float>(R * T * Wt); e->w_x = e->dmalloc<float>(R * S * Wt); e->w_y = e->dmalloc<float>(R * S * Wt);
+    e->w_fe = e->dmalloc<float>(R * e->nf * Wt); e->w_logit = e->dmalloc<float>(R * e->nf * 9 * c.discrete_num);
+    e->w_mask = e->dmalloc<unsigned char>(R * e->nf);
+    e->a_feat = amalloc(R * N * 64); e->a_dataln = amalloc(R * N * W); e->a_kv = amalloc(R * N * 2 * W); e->a_q = amalloc((size_t)T * W);
+    e->a_ln = amalloc(rows_seq * wmax); e->a_qkv = amalloc(rows_seq * 3 * wmax); e->a_att = amalloc(rows_seq * wmax); e->a_mlp = amalloc(rows_seq * fmax);
+    e->a_cat = amalloc(R * NL * 2 * W); e->a_mean = amalloc(R * NL * c.embed_dim); e->a_fein = amalloc(R * e->nf * 3 * c.codebook_dim);
+    e->a_x = amalloc(R * S * Wt);
     {
-        const size_t PR = (size_t)e->prefill_rows * T;
-        e->p_h = e->dmalloc<float>(PR * H); e->p_qkv = e->dmalloc<float>(PR * 3 * H); e->p_att = e->dmalloc<float>(PR * H);
-        e->p_y = e->dmalloc<float>(PR * H); e->p_ffn = e->dmalloc<float>(PR * c.ffn);
+        const size_t PR = R * T;
+        e->p_h = e->dmalloc<float>(PR * H); e->p_y = e->dmalloc<float>(PR * H);
+        e->a_ph = amalloc(PR * H); e->a_pqkv = amalloc(PR * 3 * H); e->a_patt = amalloc(PR * H); e->a_pffn = amalloc(PR * c.ffn);
     }
     const size_t B = c.max_batch;
     e->w_latents = e->dmalloc<float>(B * T * W); e->w_prefix = e->dmalloc<float>(B * T * H);
@@ -1019,10 +1091,11 @@ int ma_encode(ma_engine* e, const void* pc, int pc_dtype, int B, float* latents,
         if (pc_dtype != MA_DTYPE_F32 && pc_dtype != MA_DTYPE_F16) throw MaError(MA_ERR_INVALID, "pc_dtype must be F32 or F16");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const size_t pstride = (size_t)e->cfg.n_points * 6 * (pc_dtype == MA_DTYPE_F16 ? 2 : 4);
-        for (int b = 0; b < B; ++b) {
-            float* lat = latents + (size_t)b * e->T * e->cfg.enc_width;
-            encode_one(e, s, reinterpret_cast<const char*>(pc) + b * pstride, pc_dtype, lat);
-            if (prefix) prefix_one(e, s, lat, prefix + (size_t)b * e->T * e->cfg.hidden);
+        for (int b0 = 0; b0 < B; b0 += e->dense_rows) {          // the whole chunk goes through every GEMM at once (M = nb x rows)
+            const int nb = std::min(e->dense_rows, B - b0);
+            float* lat = latents + (size_t)b0 * e->T * e->cfg.enc_width;
+            encode_chunk(e, s, reinterpret_cast<const char*>(pc) + b0 * pstride, pc_dtype, nb, lat);
+            if (prefix) prefix_chunk(e, s, lat, prefix + (size_t)b0 * e->T * e->cfg.hidden, nb);
         }
     });
 }
@@ -1033,9 +1106,10 @@ int ma_to_shape_latents(ma_engine* e, const float* latents, int B, float* out, v
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const size_t n = (size_t)e->cfg.num_latents * e->cfg.enc_width;
-        for (int b = 0; b < B; ++b) {
-            shape_latents_one(e, s, latents + b * n, e->cfg.enc_width);
-            copy2d(s, e->w_lat, e->cfg.enc_width, out + b * n, e->cfg.enc_width, e->cfg.num_latents, e->cfg.enc_width);
+        for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
+            const int nb = std::min(e->dense_rows, B - b0);
+            shape_latents_chunk(e, s, latents + b0 * n, e->cfg.enc_width, RowMap{0, 0, 0}, nb);
+            HIP_CHECK(hipMemcpyAsync(out + b0 * n, e->w_lat2, (size_t)nb * n * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
     });
 }
@@ -1045,8 +1119,10 @@ int ma_process_point_feature(ma_engine* e, const float* point_feature, int B, fl
     return guarded(e, [&] {
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        for (int b = 0; b < B; ++b)
-            prefix_one(e, s, point_feature + (size_t)b * e->T * e->cfg.enc_width, prefix + (size_t)b * e->T * e->cfg.hidden);
+        for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
+            const int nb = std::min(e->dense_rows, B - b0);
+            prefix_chunk(e, s, point_feature + (size_t)b0 * e->T * e->cfg.enc_width, prefix + (size_t)b0 * e->T * e->cfg.hidden, nb);
+        }
     });
 }
 
@@ -1056,9 +1132,10 @@ int ma_get_codes(ma_engine* e, const int64_t* ids, int B, float* codes, void* st
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         const int D = e->cfg.codebook_dim, nf = e->nf;
-        for (int b = 0; b < B; ++b) {
-            hipLaunchKernelGGL(codes_gather_kernel, dim3(ceil_div(nf * 3 * D, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(ids) + (size_t)b * nf * 9,
-                               e->PF(DEC + "quantize_codebooks"), D, nf, codes + (size_t)b * nf * 3 * D, e->w_mask);
+        for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
+            const int nb = std::min(e->dense_rows, B - b0);
+            hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(nb * nf * 3 * D, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(ids) + (size_t)b0 * nf * 9,
+                               e->PF(DEC + "quantize_codebooks"), D, nb * nf, codes + (size_t)b0 * nf * 3 * D, (float*)nullptr, e->w_mask);
             HIP_CHECK(hipGetLastError());
         }
     });
@@ -1091,15 +1168,22 @@ int ma_postprocess_tokens(ma_engine* e, const int64_t* tokens, int ld_tokens, in
     });
 }
 
-int ma_detokenize(ma_engine* e, const int64_t* ids, const float* latents, int B, float* coords, void* stream) {
+int ma_detokenize_embeds(ma_engine* e, const int64_t* ids, const float* codes, const float* latents, int B, float* coords, void* stream) {
     if (!e || !ids || !latents || !coords) return MA_ERR_INVALID;
     return guarded(e, [&] {
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        for (int b = 0; b < B; ++b)
-            detok_one(e, s, reinterpret_cast<const long long*>(ids) + (size_t)b * e->nf * 9, latents + (size_t)b * e->T * e->cfg.enc_width,
-                      coords + (size_t)b * e->nf * 9);
+        const size_t nf = e->nf;
+        for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
+            const int nb = std::min(e->dense_rows, B - b0);
+            detok_chunk(e, s, reinterpret_cast<const long long*>(ids) + (size_t)b0 * nf * 9, codes ? codes + (size_t)b0 * nf * 3 * e->cfg.codebook_dim : nullptr,
+                        latents + (size_t)b0 * e->T * e->cfg.enc_width, coords + (size_t)b0 * nf * 9, nb);
+        }
     });
+}
+
+int ma_detokenize(ma_engine* e, const int64_t* ids, const float* latents, int B, float* coords, void* stream) {
+    return ma_detokenize_embeds(e, ids, nullptr, latents, B, coords, stream);
 }
 
 int ma_forward(ma_engine* e, const void* pc, int pc_dtype, int B, const ma_sample_cfg* sc, float* coords, int64_t* tokens, int32_t* lengths,
@@ -1149,7 +1233,7 @@ int ma_op_gemm(int wdtype, int impl, const float* A, int lda, const void* W, con
             r = launch_gemm_tile(t, s);
             (void)hipStreamSynchronize(s);
             (void)hipFree(Ab);
-        } else if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, impl == 2 ? 0 : impl, s);
+        } else if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, 1, s);                 // the scalar cross-check kernel
         else if (wdtype == MA_DTYPE_F32) r = launch_gemm<float>(g, impl, s);
         else throw MaError(MA_ERR_INVALID, "ma_op_gemm: wdtype");
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("ma_op_gemm: ") + hipGetErrorString(r));
@@ -1170,7 +1254,8 @@ int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
 int ma_op_layernorm(const float* x, int ldx, const float* g, const float* b, float eps, float* y, int ldy, int rows, int D, void* stream) {
     return guarded(nullptr, [&] {
         if (!x || !g || !b || !y) throw MaError(MA_ERR_INVALID, "ma_op_layernorm: null pointer");
-        hipLaunchKernelGGL(ln_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, g, b, eps, y, ldy, rows, D);
+        hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, RowMap{0, 0, 0}, g, b, eps, y, ldy,
+                           (float*)nullptr, 0, RowMap{0, 0, 0}, rows, D);
         HIP_CHECK(hipGetLastError());
     });
 }

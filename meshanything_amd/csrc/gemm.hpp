@@ -1,12 +1,12 @@
-// C[M,N] = act(A[M,K] . W[N,K]^T + bias) + R   -- the dense (M = 257 / 1057 / 4096 rows) projections of the point
-// encoder, the decoder prefill and the detokenizer (reference: every nn.Linear in transformer_blocks.py,
-// sal_perceiver.py:45,90,383-396,273-275, meshanything.py:42-80,125-132, and [3p] OPT/BERT layers at prefill).
+// C[M,N] = act(A[M,K] . W[N,K]^T + bias) + R, fp32 "exact" policy -- the dense (M = B x 257 / B x 1057 / B x 4096 rows)
+// projections of the point encoder, the decoder prefill and the detokenizer (reference: every nn.Linear in
+// transformer_blocks.py, sal_perceiver.py:45,90,383-396,273-275, meshanything.py:42-80,125-132, and [3p] OPT/BERT layers at
+// prefill).  The bf16 policy's GEMM is gemm_tile.hpp; this file keeps the exact-fp32 matrix-core kernel and a scalar
+// cross-check kernel.
 //
 // Both operands are K-contiguous ("NT"), which is exactly what MFMA fragments want.  64x64 block tile, 4 waves as
-// 2x2, each wave a 32x32 sub-tile = 2x2 MFMA 16x16 tiles.  Operands are staged global -> registers -> LDS with the
-// next tile's global loads issued before the current tile's MFMAs (loads fly under the matrix work).
-//   WT = bf16_t : A is rounded fp32->bf16 while staging, v_mfma_f32_16x16x32_bf16, BK = 32
-//   WT = float  : v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, the "exact" policy), BK = 16
+// 2x2, each wave a 32x32 sub-tile = 2x2 MFMA 16x16 tiles, v_mfma_f32_16x16x4_f32 (an exact fp32 FMA chain), BK = 16.
+// Operands are staged global -> registers -> LDS with the next tile's global loads issued before the current tile's MFMAs.
 // C/D fragment: col = lane & 15, row = (lane >> 4) * 4 + reg  (MI355X guide section 3).
 #pragma once
 #include "common.hpp"
@@ -20,6 +20,8 @@ struct GemmArgs {
     const float* R; int ldr;    // residual [M][N] or null (may alias C)
     float* C; int ldc;
     int M, N, K, act;
+    int r_mod;                  // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch: the encoder's query)
+    RowMap cmap;                // output row of logical row m (rows of a batch landing inside larger per-sample blocks)
 };
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -37,67 +39,10 @@ __device__ inline void gemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[2][2]
                 const int m = bm + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
                 if (m >= g.M) continue;
                 float v = apply_act(acc[i][j][r] + b, g.act);
-                if (g.R) v += g.R[(size_t)m * g.ldr + n];
-                g.C[(size_t)m * g.ldc + n] = v;
+                if (g.R) v += g.R[(size_t)(g.r_mod > 0 ? m % g.r_mod : m) * g.ldr + n];
+                g.C[g.cmap(m) * g.ldc + n] = v;
             }
         }
-}
-
-__global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs g) {
-    constexpr int BK = 32, LDS_LD = 40;                 // 80-byte rows: 16-byte aligned, spreads banks
-    __shared__ __attribute__((aligned(16))) bf16_t As[64 * LDS_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[64 * LDS_LD];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int bm = blockIdx.y * 64, bn = blockIdx.x * 64;
-    const bf16_t* W = reinterpret_cast<const bf16_t*>(g.W);
-    const int srow = tid >> 2, skc = (tid & 3) * 8;
-    const int am = bm + srow, wnrow = bn + srow;
-    const bool a_ok = am < g.M, w_ok = wnrow < g.N;
-    const float* ap = g.A + (size_t)(a_ok ? am : 0) * g.lda + skc;
-    const bf16_t* wp = W + (size_t)(w_ok ? wnrow : 0) * g.K + skc;
-
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-    u32x4 wr = {0, 0, 0, 0};
-    if (a_ok) { a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4); }
-    if (w_ok) wr = *reinterpret_cast<const u32x4*>(wp);
-
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
-        // registers -> LDS (A rounded to bf16 here: the bf16 policy's activation rounding point)
-        u32x4 apk;
-        apk.x = (uint32_t)f2bf(a0.x) | ((uint32_t)f2bf(a0.y) << 16);
-        apk.y = (uint32_t)f2bf(a0.z) | ((uint32_t)f2bf(a0.w) << 16);
-        apk.z = (uint32_t)f2bf(a1.x) | ((uint32_t)f2bf(a1.y) << 16);
-        apk.w = (uint32_t)f2bf(a1.z) | ((uint32_t)f2bf(a1.w) << 16);
-        *reinterpret_cast<u32x4*>(&As[srow * LDS_LD + skc]) = apk;
-        *reinterpret_cast<u32x4*>(&Bs[srow * LDS_LD + skc]) = wr;
-        __syncthreads();
-        // next tile's global loads fly under this tile's MFMAs
-        const int kn = k0 + BK;
-        if (kn < g.K) {
-            if (a_ok) { a0 = *reinterpret_cast<const f32x4*>(ap + kn); a1 = *reinterpret_cast<const f32x4*>(ap + kn + 4); }
-            if (w_ok) wr = *reinterpret_cast<const u32x4*>(wp + kn);
-        }
-        bf16x8_t af[2], bfr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            af[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 32 + i * 16 + (lane & 15)) * LDS_LD + (lane >> 4) * 8]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            bfr[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wn * 32 + j * 16 + (lane & 15)) * LDS_LD + (lane >> 4) * 8]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __syncthreads();
-    }
-    gemm_epilogue(g, acc, bm, bn, wm, wn, lane);
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
@@ -167,8 +112,8 @@ __global__ __launch_bounds__(256) void gemm_ref_kernel(GemmArgs g) {
         acc = fmaf(av, wv, acc);
     }
     float v = apply_act(acc + (g.bias ? g.bias[n] : 0.f), g.act);
-    if (g.R) v += g.R[(size_t)m * g.ldr + n];
-    g.C[(size_t)m * g.ldc + n] = v;
+    if (g.R) v += g.R[(size_t)(g.r_mod > 0 ? m % g.r_mod : m) * g.ldr + n];
+    g.C[g.cmap(m) * g.ldc + n] = v;
 }
 
 template <typename WT>
@@ -181,7 +126,7 @@ inline hipError_t launch_gemm(const GemmArgs& g, int impl, hipStream_t s) {
     if (g.K % 32 != 0 || g.lda % 4 != 0) return hipErrorInvalidValue;
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
     if constexpr (sizeof(WT) == 4) hipLaunchKernelGGL(gemm_mfma_f32_kernel, grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(gemm_mfma_bf16_kernel, grid, dim3(256), 0, s, g);
+    else return hipErrorInvalidValue;                       // bf16 weights: gemm_tile.hpp (bf16 activations)
     return hipGetLastError();
 }
 

@@ -32,6 +32,8 @@ struct GemmTArgs {
     float* C; int ldc;              // fp32 output or null
     bf16_t* Cb; int ldcb;           // bf16 output or null
     int M, N, K, act;
+    int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
+    RowMap cmap;                    // output row of logical row m
 };
 
 __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
@@ -126,25 +128,26 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
         for (int j = 0; j < TM; ++j) {
             const int m = bm + wm * (BM / 2) + j * 16 + fr;
             if (m >= g.M) continue;
+            const size_t mr = (size_t)(g.r_mod > 0 ? m % g.r_mod : m), mo = g.cmap(m);
             f32x4 v = acc[i][j];
             v.x = apply_act(v.x + b4.x, g.act); v.y = apply_act(v.y + b4.y, g.act);
             v.z = apply_act(v.z + b4.z, g.act); v.w = apply_act(v.w + b4.w, g.act);
             if (full) {
-                if (g.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(g.R + (size_t)m * g.ldr + n0); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-                if (g.C) *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + n0) = v;
+                if (g.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(g.R + mr * g.ldr + n0); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                if (g.C) *reinterpret_cast<f32x4*>(g.C + mo * g.ldc + n0) = v;
                 if (g.Cb) {
                     u32x2 pk;
                     pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
                     pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-                    *reinterpret_cast<u32x2*>(g.Cb + (size_t)m * g.ldcb + n0) = pk;
+                    *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + n0) = pk;
                 }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
                 for (int r = 0; r < 4 && n0 + r < g.N; ++r) {
                     float t = vv[r];
-                    if (g.R) t += g.R[(size_t)m * g.ldr + n0 + r];
-                    if (g.C) g.C[(size_t)m * g.ldc + n0 + r] = t;
-                    if (g.Cb) g.Cb[(size_t)m * g.ldcb + n0 + r] = f2bf(t);
+                    if (g.R) t += g.R[mr * g.ldr + n0 + r];
+                    if (g.C) g.C[mo * g.ldc + n0 + r] = t;
+                    if (g.Cb) g.Cb[mo * g.ldcb + n0 + r] = f2bf(t);
                 }
             }
         }

@@ -1,4 +1,5 @@
-// Small row-wise / gather / sampling kernels around the GEMMs.  Each cites the reference lines it implements.
+// Token post-processing, coordinate argmax and the token pick / sampler (the batched row-wise kernels of the dense phases
+// live in dense_ops.hpp).  Each cites the reference lines it implements.
 #pragma once
 #include "common.hpp"
 #include "state.hpp"
@@ -6,72 +7,6 @@
 namespace ma {
 
 constexpr int TOK_BOS = 0, TOK_EOS = 1, TOK_PAD = 2;      // meshanything.py:102-104
-
-// FourierEmbedder.forward (embedder.py:87-105, logspace, include_pi=False, include_input=True) + normals concat
-// (sal_perceiver.py:87-89): out[i] = [x(3) | sin(x_d * 2^f) (d-major) | cos(...) | normal(3) | 0-pad to ld]
-template <typename PT>
-__global__ void fourier_kernel(const PT* __restrict__ pc, int n_points, int F, float* __restrict__ out, int ld) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_points * ld) return;
-    const int i = idx / ld, col = idx - i * ld;
-    const PT* p = pc + (size_t)i * 6;
-    float v = 0.f;
-    if (col < 3) v = (float)p[col];
-    else if (col < 3 + 6 * F) {
-        const int j = (col - 3) % (3 * F);
-        const int dim = j / F, fr = j - dim * F;
-        const float arg = (float)p[dim] * (float)(1 << fr);
-        v = (col < 3 + 3 * F) ? sinf(arg) : cosf(arg);
-    } else if (col < 6 + 6 * F) v = (float)p[3 + col - (3 + 6 * F)];
-    out[idx] = v;
-}
-
-// nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32).  y may alias x.
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
-                                                      const float* __restrict__ b, float eps, float* __restrict__ y, int ldy,
-                                                      int rows, int D) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* xr = x + (size_t)row * ldx;
-    float s = 0.f;
-    for (int k = lane; k < D; k += 64) s += xr[k];
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-    for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-    float* yr = y + (size_t)row * ldy;
-    for (int k = lane; k < D; k += 64) yr[k] = (xr[k] - mean) * rstd * g[k] + b[k];
-}
-
-// out[i][n] = (mask == null || mask[i] ? in[i][n] : 0) + (t0 ? t0[n] : 0) + (tab ? tab[(i + row0) * ld_tab + n] : 0)
-//  - decoder prefill: prefix + cond_embed[0] + embed_positions[2 + i]         (shape_opt.py:331-337, 359-364)
-//  - detokenizer:     point feature + point_pe[i]; masked face embeds + pos_embedding[i]   (meshanything.py:47, 58-60)
-// tab_mod > 0: the table restarts every tab_mod rows (a batch of samples stacked along the rows)
-__global__ void add_rows_kernel(const float* __restrict__ in, int ld_in, const unsigned char* __restrict__ mask,
-                                const float* __restrict__ t0, const float* __restrict__ tab, int ld_tab, int row0,
-                                float* __restrict__ out, int ld_out, int rows, int cols, int tab_mod) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const int i = idx / cols, n = idx - i * cols;
-    float v = (mask == nullptr || mask[i]) ? in[(size_t)i * ld_in + n] : 0.f;
-    if (t0) v += t0[n];
-    if (tab) v += tab[(size_t)((tab_mod > 0 ? i % tab_mod : i) + row0) * ld_tab + n];
-    out[(size_t)i * ld_out + n] = v;
-}
-
-__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const int i = idx / cols, n = idx - i * cols;
-    dst[(size_t)i * ldd + n] = src[(size_t)i * lds + n];
-}
-
-__global__ void zero_masked_rows_kernel(float* __restrict__ x, int ld, const unsigned char* __restrict__ mask, int rows, int cols) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * cols) return;
-    const int i = idx / cols, n = idx - i * cols;
-    if (!mask[i]) x[(size_t)i * ld + n] = 0.f;
-}
 
 // meshanything.py:141-142,163-172: eos-pad the generated tokens to 9F+2, drop first and last, specials -> -1, others -= 3
 __global__ void postprocess_tokens_kernel(const long long* __restrict__ tokens, int ld_tokens, int n_generated, int max_new,
@@ -83,25 +18,6 @@ __global__ void postprocess_tokens_kernel(const long long* __restrict__ tokens, 
     const int src = j + 1;                                      // outputs[:, 1:-1]
     long long t = src < n_generated ? tokens[(size_t)b * ld_tokens + src] : (long long)TOK_EOS;
     ids[idx] = (t == TOK_BOS || t == TOK_EOS || t == TOK_PAD) ? -1 : t - 3;
-}
-
-// get_codes (meshanything.py:178-212) fused with the 'b (nf nv) d -> b nf (nv d)' rearrange (:53) and the face mask (:57):
-// out[f][v*D + d] = sum_{q<3} codebook[ids[f*9 + v*3 + q]][d] (pad -1 contributes 0); mask[f] = all nine ids != -1
-__global__ void codes_gather_kernel(const long long* __restrict__ ids, const float* __restrict__ codebook, int D, int nf,
-                                    float* __restrict__ out, unsigned char* __restrict__ mask) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nf * 3 * D) return;
-    const int f = idx / (3 * D), rem = idx - f * 3 * D, v = rem / D, d = rem - v * D;
-    const long long* ip = ids + (size_t)f * 9 + v * 3;
-    float c[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { const long long id = ip[q]; c[q] = id < 0 ? 0.f : codebook[(size_t)id * D + d]; }
-    out[idx] = (c[0] + c[1]) + c[2];
-    if (rem == 0) {
-        bool ok = true;
-        for (int q = 0; q < 9; ++q) ok = ok && ids[(size_t)f * 9 + q] != -1;
-        mask[f] = ok ? 1 : 0;
-    }
 }
 
 // meshanything.py:69-78 + undiscretize (214-223): argmax over the discrete bins (lowest index wins ties),

@@ -196,8 +196,9 @@ class Engine:
         self._check(self.lib.ma_postprocess_tokens(self.h, _ptr(t), ld, B, n, _ptr(ids), _stream_ptr()))
         return ids
 
-    def detokenize(self, ids: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
-        """tokenizer(ids, get_codes(ids), point_feature=latents) (meshanything.py:173-174) -> (B, F, 3, 3)."""
+    def detokenize(self, ids: torch.Tensor, latents: torch.Tensor, codes: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tokenizer(ids, codes, point_feature=latents) (meshanything.py:50-80, 173-174) -> (B, F, 3, 3).  codes = the
+        reference's `input_embeds` (B, 3F, codebook_dim); None: get_codes(ids) is computed inside the launch chain."""
         cfg = self.cfg
         ids = ids.to(self.device, torch.int64)
         ids = ids.reshape(ids.shape[0], -1).contiguous()            # the reference reshapes too (meshanything.py:51)
@@ -207,8 +208,12 @@ class Engine:
             raise ValueError(f"ids must be (B, 9*n_max_faces = {cfg.n_max_faces * 9}), got {tuple(ids.shape)}")
         if tuple(latents.shape) != (B, cfg.cond_length, cfg.enc_width):
             raise ValueError(f"point_feature must be ({B}, {cfg.cond_length}, {cfg.enc_width}), got {tuple(latents.shape)}")
+        if codes is not None:
+            codes = codes.to(self.device, torch.float32).contiguous()
+            if tuple(codes.shape) != (B, cfg.n_max_faces * 3, cfg.codebook_dim):
+                raise ValueError(f"input_embeds must be ({B}, {cfg.n_max_faces * 3}, {cfg.codebook_dim}), got {tuple(codes.shape)}")
         coords = torch.empty(B, cfg.n_max_faces, 3, 3, dtype=torch.float32, device=self.device)
-        self._check(self.lib.ma_detokenize(self.h, _ptr(ids), _ptr(latents), B, _ptr(coords), _stream_ptr()))
+        self._check(self.lib.ma_detokenize_embeds(self.h, _ptr(ids), _ptr(codes), _ptr(latents), B, _ptr(coords), _stream_ptr()))
         return coords
 
     def forward(self, pc_normal: torch.Tensor, sampling: bool = False, max_new_tokens: Optional[int] = None,

@@ -90,13 +90,12 @@ class Tokenizer:
         self.num_quantizers = 3
 
     def __call__(self, input_ids: torch.Tensor, input_embeds: Optional[torch.Tensor] = None, point_feature: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """ids (B, 9F) in [-1, codebook), codes (B, 3F, D) as returned by get_codes, point_feature (B, 257, 768) ->
-        (B, F, 3, 3) fp32 vertex coordinates, NaN rows = invalid faces.  `input_embeds` is a pure function of
-        `input_ids` and the checkpoint's codebook (get_codes); the engine recomputes it inside the detokenizer launch
-        chain, so the argument is accepted for signature compatibility and not read."""
+        """ids (B, 9F) in [-1, codebook), codes (B, 3F, D) (what get_codes returns, or any other embeddings of that shape),
+        point_feature (B, 257, 768) -> (B, F, 3, 3) fp32 vertex coordinates, NaN rows = invalid faces.  `input_embeds` is used
+        as the face codes exactly as the reference uses it (meshanything.py:53-55); None: get_codes(input_ids)."""
         if point_feature is None:
             raise ValueError("tokenizer(...) needs point_feature (the raw 257x768 encoder latents, meshanything.py:174)")
-        return self._e.detokenize(input_ids, point_feature)
+        return self._e.detokenize(input_ids, point_feature, codes=input_embeds)
 
     forward = __call__
 

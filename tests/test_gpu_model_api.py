@@ -83,6 +83,13 @@ def test_each_reference_call(env):
     assert coords.shape == (2, cfg.n_max_faces, 3, 3) and coords.dtype == torch.float32
     assert torch.equal(torch.isnan(coords.cpu()), torch.isnan(ref_coords))
     assert int((torch.nan_to_num(coords.cpu(), nan=9.0) != torch.nan_to_num(ref_coords, nan=9.0)).sum()) <= 2
+    # input_embeds is READ, as in the reference (meshanything.py:53-55): other embeddings -> the oracle's answer for those
+    other = torch.roll(ref_codes, shifts=1, dims=1) * 0.5
+    coords2 = m.tokenizer(ids.cuda(), other.cuda(), point_feature=pf)
+    ref2 = o.detokenize(ids, other, ref_pf)
+    assert int((torch.nan_to_num(coords2.cpu(), nan=9.0) != torch.nan_to_num(ref2, nan=9.0)).sum()) <= 2
+    assert not torch.equal(torch.nan_to_num(coords2.cpu(), nan=9.0), torch.nan_to_num(coords.cpu(), nan=9.0))
+    assert torch.equal(torch.nan_to_num(m.tokenizer(ids.cuda(), None, point_feature=pf), nan=9.0), torch.nan_to_num(coords, nan=9.0))
     del ref_tokens
 
 
