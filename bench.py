@@ -55,6 +55,46 @@ def kv_bytes_per_step(cfg: MAConfig, length: int, esz: int) -> int:
     return cfg.layers * 2 * cfg.hidden * esz * length
 
 
+# algorithmic GFLOP per shape of the dense phases: encoder 108.5 + prefix projections 0.8, prefill 158.5, detokenizer 115.6
+DENSE_GFLOP = {"encode_prefix": 109.3, "prefill": 158.5, "detokenize": 115.6}
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md)
+
+
+def dense_phase_table(eng, cfg: MAConfig, batches=(16, 64), iters: int = 3):
+    """Encoder + prefix, prefill (generate with one new token) and detokenizer for a batch of synthetic clouds: ms, TFLOP/s and
+    fraction of the dense bf16 MFMA peak (time-derived; the PMC MFMA-busy view of the same phases is under profiles/)."""
+    out = []
+    g = torch.Generator().manual_seed(0)
+    for B in batches:
+        if B > cfg.max_batch:
+            continue
+        d = torch.randn(B, cfg.n_points, 3, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        x = torch.cat([d * 0.9, d], dim=-1).half().cuda()
+        ids = torch.randint(0, cfg.codebook_size, (B, cfg.n_max_faces * 9), generator=g).cuda()
+        acc = {k: [] for k in DENSE_GFLOP}
+        for it in range(iters + 1):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            lat, prefix = eng.encode(x)
+            ev[1].record()
+            eng.generate(prefix, max_new_tokens=1, suppress_eos=True)
+            ev[2].record()
+            eng.detokenize(ids, lat)
+            ev[3].record()
+            torch.cuda.synchronize()
+            if it:
+                for i, k in enumerate(DENSE_GFLOP):
+                    acc[k].append(ev[i].elapsed_time(ev[i + 1]))
+        ms = {k: float(np.median(v)) for k, v in acc.items()}
+        tot_ms = sum(ms.values())
+        tot_gf = sum(DENSE_GFLOP.values()) * B
+        row = {"batch": B, "ms": {k: round(v, 3) for k, v in ms.items()}, "TFLOPs": {k: round(DENSE_GFLOP[k] * B / ms[k], 1) for k in ms},
+               "all_ms": round(tot_ms, 3), "all_TFLOPs": round(tot_gf / tot_ms, 1), "frac_of_bf16_mfma_peak": round(tot_gf / tot_ms / MFMA_PEAK_TFLOPS, 4)}
+        out.append(row)
+    return out
+
+
 def cpu_baseline(cfg: MAConfig, sd, x: torch.Tensor, decode_steps: int = 384):
     """The oracle (a CPU port of the reference arithmetic, fp32, PyTorch threads = host cores) on a bounded sample of the
     same workload: encode + prefill + `decode_steps` greedy KV-cache steps for the same cloud and weights."""
@@ -225,6 +265,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))
         batched = None
+        dense = None
         if args.batch == 1 and not args.no_batched_table and args.dtype == "bf16" and world == 1:
             # configs 3-5 in brief: the decode step when 8 / 64 shapes share the weight stream (mid context, graph replay)
             eng.close()
@@ -240,6 +281,7 @@ def main():
                 byts = wbytes + Bb * kv_bytes_per_step(cfg_b, mid, 2)
                 batched.append({"batch": Bb, "kv_len": mid, "decode_step_ms": round(sb, 4), "face_tokens_per_s": round(Bb / (sb * 1e-3), 1),
                                 "GBps": round(byts / (sb * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(byts / (sb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            dense = dense_phase_table(eng_b, cfg_b)
             eng_b.close()
         total_tokens = world * args.steps * tokens_per_step
         res = {
@@ -256,7 +298,7 @@ def main():
                                       f"{args.faces}-face cap ({cfg.max_new_tokens} tokens/shape, eos suppressed), KV-cache decode, hipGraph"),
                        "global_batch": world * args.batch, "tokens_per_mesh": cfg.max_new_tokens, "parallelism": f"dp{world} (independent shapes, weights broadcast once)",
                        "weights": "seeded random init in the reference key layout (no checkpoint available offline)"},
-            "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+            "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "dense_phases": dense, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
             "weights_load_s": round(t_load, 2), "roofline": roofline, "cpu_baseline": cpu,
         }
         if real_stdout is not None:

@@ -32,8 +32,8 @@ __global__ void fourier2_kernel(const PT* __restrict__ pc, int n_rows, int F, AT
     st_act<AT>(out + idx, v);
 }
 
-// nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32): x fp32 -> y32 (fp32, optional) and
-// ya (AT, optional).  y32 may alias x.
+// nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32, the row held in registers: one global
+// read, 16-byte accesses): x fp32 -> y32 (fp32, optional) and ya (AT, optional).  y32 may alias x.  D % 4 == 0, D <= 4096.
 template <typename AT>
 __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__ x, int ldx, RowMap xin, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, float* y32, int ld32, AT* __restrict__ ya,
@@ -41,17 +41,44 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + xin(row) * ldx;
+    constexpr int NV = 16;                                // float4 chunks per lane: D <= 64 * 4 * 16
+    const int nq = D >> 2;
+    f32x4 v[NV];
     float s = 0.f;
-    for (int k = lane; k < D; k += 64) s += xr[k];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = lane + 64 * j;
+        if (q < nq) { v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * q); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+    }
     const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-    for (int k = lane; k < D; k += 64) { const float d = xr[k] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    float qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (lane + 64 * j < nq) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)D + eps);
     const size_t orow = yout(row);
-    for (int k = lane; k < D; k += 64) {
-        const float v = (xr[k] - mean) * rstd * g[k] + b[k];
-        if (y32) y32[orow * ld32 + k] = v;
-        if (ya) st_act<AT>(ya + orow * lda + k, v);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int q = lane + 64 * j;
+        if (q < nq) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * q), b4 = *reinterpret_cast<const f32x4*>(b + 4 * q);
+            f32x4 o;
+            o.x = (v[j].x - mean) * rstd * g4.x + b4.x; o.y = (v[j].y - mean) * rstd * g4.y + b4.y;
+            o.z = (v[j].z - mean) * rstd * g4.z + b4.z; o.w = (v[j].w - mean) * rstd * g4.w + b4.w;
+            if (y32) *reinterpret_cast<f32x4*>(y32 + orow * ld32 + 4 * q) = o;
+            if (ya) {
+                if constexpr (sizeof(AT) == 4) *reinterpret_cast<f32x4*>(ya + orow * lda + 4 * q) = o;
+                else {
+                    u32x2 pk;
+                    pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16); pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+                    *reinterpret_cast<u32x2*>(ya + orow * lda + 4 * q) = pk;
+                }
+            }
+        }
     }
 }
 

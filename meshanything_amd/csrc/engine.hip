@@ -840,11 +840,11 @@ void build_engine(ma_engine* e) {
     }
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_state), MB * sizeof(DecState)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_tokens), MB * e->maxnew * sizeof(long long)));
-    // dense workspace: R = dense_rows samples stacked along the rows (16 x 4096 point rows / 16 x 257 latent rows / 16 x 1057
-    // detokenizer rows per pass: ~1.3 GB at the 350M shape under the bf16 policy)
+    // dense workspace: R = dense_rows samples stacked along the rows (R x 4096 point rows / R x 257 latent rows / R x 1057
+    // detokenizer rows per pass)
     const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S, NL = c.num_latents;
     e->act_elem = e->bf16 ? 2 : 4;
-    e->dense_rows = std::min(c.max_batch, 16);
+    e->dense_rows = std::min(c.max_batch, 64);                        // 64 x 4096 point rows per pass: 5 GB of workspace at the 350M shape (bf16 policy)
     e->prefill_rows = e->dense_rows;
     const size_t R = e->dense_rows;
     const size_t rows_seq = R * std::max(T, S);                      // rows of the latent / token streams

@@ -165,8 +165,11 @@ inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
         if (r != hipSuccess) return r;
         attr = true;
     }
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 64)
+    const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160)
         hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), BIG, s, g);
+    else if (g.K % 64 == 0 && g.M > 64 && g.N > 32)          // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
+        hipLaunchKernelGGL((gemm_tile_kernel<128, 64, 64>), dim3((g.N + 63) / 64, (g.M + 127) / 128), dim3(256), 2 * (128 + 64) * 64 * 2, s, g);
     else
         hipLaunchKernelGGL((gemm_tile_kernel<64, 64, 32>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 2 * (64 + 64) * 32 * 2, s, g);
     return hipGetLastError();
