@@ -29,6 +29,7 @@
 #include "gemv.hpp"
 #include "misc.hpp"
 #include "persist.hpp"
+#include "qkv_attn.hpp"
 #include "state.hpp"
 #include "weights.hpp"
 
@@ -103,6 +104,9 @@ struct ma_engine {
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
+    int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
+    u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
+    unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
     int opt_decode_impl = 0;         // 0: chain of launches; 1: one persistent launch per step (when eligible)
     int n_cus = 0;
     bool persist_shape = false;      // shape / device eligibility (fixed at creation)
@@ -413,6 +417,8 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     gemm_dec(e, s, g, tm);
 }
 
+bool fuse_qkv_attn(ma_engine* e) { return e->opt_fuse_qkv_attn && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
+
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
 void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
     const ma_config& c = e->cfg;
@@ -423,6 +429,19 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     float* h1 = e->d_h1 + r0 * H; float* ffn = e->d_ffn + r0 * c.ffn; float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
     const float* resid = ln_g ? h0 : x_in;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
+    if (fuse_qkv_attn(e)) {
+        // q, k, v projection + split-KV attention in one launch (qkv_attn.hpp): the exchange between them stays inside a head
+        QkvAttnArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? h0 : nullptr;
+        a.kcache = reinterpret_cast<bf16_t*>(e->kplane(rw.r0, l)); a.vcache = reinterpret_cast<bf16_t*>(e->vplane(rw.r0, l)); a.max_seq = e->maxseq; a.hidden = H;
+        a.st = e->d_st + r0; a.len_override = len_override; a.layer = l; a.ws = part; a.gran = e->d_qkv_gran + r0 * 3 * H; a.err = e->d_chain_err;
+        a.x_stride = H; a.xn_stride = H; a.kv_row_stride = kv_row_elems;
+        a.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
+        if (tm.on(1)) {
+            hipError_t r = launch_qkv_attn(a, c.heads, B, s);
+            if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("qkv_attn launch failed: ") + hipGetErrorString(r));
+        }
+    } else {
     {   // q,k,v = W h + b ; k,v appended to the cache in place ([3p] OPTAttention; 4.39.3 grows it with torch.cat)
         GemvArgs a = gemv_base(e, rw);
         a.W = w.qkv_w; a.bias = w.qkv_b; a.x = x_in; a.x_stride = H; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? h0 : nullptr; a.xn_stride = H;
@@ -436,6 +455,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems)
                                : launch_attn_decode<float>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 0, part, s, tr, B, H, kv_row_elems);
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+    }
     }
     {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
         GemvArgs a = gemv_base(e, rw);
@@ -525,6 +545,17 @@ void check_persist_error(ma_engine* e, hipStream_t s) {
         HIP_CHECK(hipMemsetAsync(e->d_err, 0, sizeof(unsigned), s));
         throw MaError(MA_ERR_HIP, "persistent decode step: a bounded wait expired (code " + std::to_string(code) +
                                   ": 1 loader, 2 comm, 4 compute, 8 gather) -- the 256 workgroups were not all resident, or a hand-off was lost");
+    }
+}
+
+// the fused q/k/v + attention launch reports an expired (bounded) granule sweep through a device word
+void check_chain_error(ma_engine* e, hipStream_t s) {
+    if (!fuse_qkv_attn(e)) return;
+    HIP_CHECK(hipMemcpyAsync(e->h_chain_err, e->d_chain_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (*e->h_chain_err) {
+        HIP_CHECK(hipMemsetAsync(e->d_chain_err, 0, sizeof(unsigned), s));
+        throw MaError(MA_ERR_HIP, "fused q/k/v + attention launch: the in-launch exchange timed out (not all blocks of the grid resident?)");
     }
 }
 
@@ -651,6 +682,8 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     st.seed = sc.seed; st.uniforms = sc.uniforms; st.row = 0; st.max_new = maxn;
     hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, e->d_st, st, B);
     HIP_CHECK(hipGetLastError());
+    // the fused q/k/v + attention launch tags its exchange with the cache position, which restarts here
+    HIP_CHECK(hipMemsetAsync(e->d_qkv_gran, 0, (size_t)e->cfg.max_batch * 3 * e->cfg.hidden * sizeof(u64), s));
 }
 
 ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
@@ -700,6 +733,7 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
         HIP_CHECK(hipMemcpyAsync(e->h_state, e->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         if (impl == 1) check_persist_error(e, s);
+        else check_chain_error(e, s);
         finished = true;
         for (int b = 0; b < B; ++b) finished = finished && e->h_state[b].finished != 0;
     }
@@ -816,6 +850,10 @@ void build_engine(ma_engine* e) {
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
+    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(1);
+    HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
+    HIP_CHECK(hipMemset(e->d_chain_err, 0, sizeof(unsigned)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
     HIP_CHECK(hipMemset(e->d_st, 0, MB * sizeof(DecState)));
@@ -939,6 +977,7 @@ void ma_engine_destroy(ma_engine* e) {
     if (e->kv) (void)hipFree(e->kv);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_err) (void)hipHostFree(e->h_err);
+    if (e->h_chain_err) (void)hipHostFree(e->h_chain_err);
     if (e->h_tokens) (void)hipHostFree(e->h_tokens);
     delete e;
 }
@@ -952,6 +991,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
+        else if (n == "fuse_qkv_attn") { e->opt_fuse_qkv_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_impl") {
             if (value != 0 && value != 1) throw MaError(MA_ERR_INVALID, "decode_impl must be 0 (launch chain) or 1 (persistent step)");
             e->opt_decode_impl = (int)value;

@@ -369,6 +369,7 @@ __device__ __forceinline__ bool ps_attention(lptr lds, gkv kplane_h, gkv vplane_
         for (int u = 0; u < G::U; ++u) { const int p = base + u * G::PPW; vr[u] = ld_stream16(vh + (size_t)(p < end ? p : start) * 64); }
     };
     if (nround > 0) issue(0, kA, vA);                 // the cached rows do not depend on q: in flight while q travels
+    asm volatile("" ::: "memory");                    // (keeps hipcc from sinking the loads below the wait)
     if (!ps_wait(ctrl, PC_GATHERED, need_g + 1, t0, gerr, PS_ERR_COMPUTE)) return false;
     const float* qg = reinterpret_cast<const float*>(smem + PL_QKVG);
     float qv[G::EPL];

@@ -1,0 +1,221 @@
+// Fused q/k/v projection + split-KV decode attention of one layer, batch-1 launch chain (bf16 policy, hidden = 1024).
+//
+// Replaces two launches of the chain -- the fused-QKV GEMV (gemv.hpp, EPI_QKV; [3p] OPTAttention q/k/v projections reached from
+// shape_opt.py:403-410) and the split-KV attention (attn_decode.hpp; [3p] OptFlashAttention2 + the per-step torch.cat) -- by one:
+// attention of head h needs only the 192 q/k/v outputs of head h, so the exchange between the two is not all-to-all.  Block
+// (chunk c, head h) of the 16 x heads grid
+//   1. issues, in its first instructions: the input vector + LayerNorm parameters, its 12 weight rows (q, k, v rows
+//      64 h + 4 c + wave of the fused [3H][H] matrix: 24 KB), and round 0 of its K / V cache rows (they depend on nothing);
+//   2. runs the GEMV prologue (LayerNorm of the post-LN stream, common.hpp) and its 12 dot products -- the arithmetic of
+//      gemv_kernel<bf16, 1, 2, *, *>, bit for bit;
+//   3. publishes the 12 values as 8-byte {epoch, value} granules (one sc1 store each; MI355X guide, Guideline 16 R2) and one
+//      wave sweeps the 64 granules of q_h (the block holding the newest position also k_h, v_h: 192) until every tag carries this
+//      launch's epoch -- the exchange stays among the 16 blocks of a head.  Epoch = position * 32 + layer + 1: strictly
+//      increasing within a generation, the buffer is zeroed when the position restarts;
+//   4. attends over its chunk with the shared round / merge code of attn_decode.hpp (the newest position's K / V rows come from the
+//      granules, and are written to the cache for later steps) and writes the (m, l, o[64]) partial for the out_proj launch.
+// One launch boundary and one dependent-vector round trip less per layer; the K / V stream is in flight while q is computed.
+// Every block of the grid must be resident (256 x batch blocks of 256 threads: any device with >= 32 CUs); the sweep is bounded
+// (20 ms) and raises the engine's error word instead of hanging.
+#pragma once
+#include "attn_decode.hpp"
+#include "common.hpp"
+#include "gemv.hpp"
+#include "persist.hpp"
+#include "state.hpp"
+
+namespace ma {
+
+struct QkvAttnArgs {
+    const bf16_t* W; const float* bias;                  // fused [3 hidden][hidden] projection, [3 hidden] bias
+    const float* x; const float* ln_g; const float* ln_b; float ln_eps; float* xn_out;      // as GemvArgs (ln_g == null: no LayerNorm)
+    bf16_t* kcache; bf16_t* vcache; int max_seq; int hidden;
+    const DecState* st; int len_override; int layer;
+    float* ws;                                           // split-KV partials (attn_workspace_floats per batch row)
+    u64* gran;                                           // [batch][3 hidden] granules
+    unsigned* err;
+    int x_stride, xn_stride; size_t kv_row_stride;
+    unsigned long long* trace;
+};
+constexpr unsigned QA_ERR_GATHER = 16;
+
+template <int PRO>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
+    typedef AttnGeom<bf16_t> G;
+    constexpr int KC = 1024;
+    __shared__ __attribute__((aligned(16))) float xl[KC];
+    __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float qg[64];            // q_h, already rounded to bf16 (one conversion per lane, by the sweeping wave)
+    __shared__ __attribute__((aligned(16))) bf16_t kvg[128];        // newest position's k_h | v_h as bf16 (what the cache holds)
+    __shared__ AttnMergeLds<bf16_t> S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = blockIdx.x, h = blockIdx.y, nheads = gridDim.y, brow = blockIdx.z;
+    const int Hd = a.hidden;
+    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    const float* x = a.x + (size_t)brow * a.x_stride;
+    const DecState sv = a.st[brow];
+    const int len = a.len_override >= 0 ? a.len_override : sv.pos + 1;
+    const int pos = len - 1;                             // the newest position: its K / V rows are produced by this launch
+    const unsigned epoch = (unsigned)pos * 32u + (unsigned)a.layer + 1u;
+    const int per = (len + ATTN_NCHUNK - 1) / ATTN_NCHUNK, c_last = (len - 1) / per;
+    const int start = c * per, end = min(len, start + per);
+    const int nround = (max(end - start, 0) + 127) >> 7;
+
+    // ---- (1) loads, in consumption order: input vector (+ LayerNorm parameters), weight rows, bias, round 0 of the cache rows -----
+    f32x4 xv[1], gv[1], bv[1];
+    float x0 = 0.f;
+    xv[0] = *reinterpret_cast<const f32x4*>(x + tid * 4);
+    if constexpr (PRO == PRO_LN) {
+        x0 = x[0];
+        gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
+        bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
+    }
+    const int row = 64 * h + 4 * c + w;                  // this wave's row inside each of the q, k, v blocks of the fused matrix
+    u32x4 wv[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const bf16_t* wr = a.W + (size_t)(p * Hd + row) * KC;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wv[p][i] = ld_stream16(wr + (i * 64 + lane) * 8);
+    }
+    float bq[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bq[p] = a.bias[p * Hd + row];
+    const int slot = lane / G::LPP, dsub = lane % G::LPP, woff = w * 32;
+    const bf16_t* kh = a.kcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
+    const bf16_t* vh = a.vcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
+    u32x4 kA[G::U], vA[G::U], kB[G::U], vB[G::U];
+    auto issue = [&](int r, u32x4 (&kr)[G::U], u32x4 (&vr)[G::U]) {
+        const int base = start + (r << 7) + woff + slot;
+#pragma unroll
+        for (int u = 0; u < G::U; ++u) { const int p = base + u * G::PPW; kr[u] = ld_stream16(kh + (size_t)(p < end ? p : start) * 64); }
+#pragma unroll
+        for (int u = 0; u < G::U; ++u) { const int p = base + u * G::PPW; vr[u] = ld_stream16(vh + (size_t)(p < end ? p : start) * 64); }
+    };
+    if (nround > 0) issue(0, kA, vA);
+    asm volatile("" ::: "memory");                       // pin the cache-row loads HERE (hipcc would sink them below the exchange)
+
+    // ---- (2) prologue + dot products: gemv_kernel<bf16_t, 1, 2, *, PRO> for the rows of this block --------------------------------
+    if constexpr (PRO == PRO_LN) ln_block_onepass<1>(xv, gv, bv, x0, tid, KC / 4, KC, a.ln_eps, red);
+    if (a.xn_out && c == 0 && h == 0) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)brow * a.xn_stride + tid * 4) = xv[0];
+    {
+        f32x4 r = xv[0];
+        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
+    }
+    __syncthreads();
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        float xs[8];
+#pragma unroll
+        for (int v = 0; v < 8; v += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
+            xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            float wf[8];
+            unpack16<bf16_t>(wv[p][i], wf);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc[p] = fmaf(wf[v], xs[v], acc[p]);
+        }
+    }
+    float out3[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { float v = wave_sum(acc[p]); v += bq[p]; out3[p] = v; }
+    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- (3) exchange inside the head: publish 3 values per wave, wave 0 sweeps what this block needs -----------------------------
+    u64* gran = a.gran + (size_t)brow * 3 * Hd;
+    if (lane < 3) ps_publish(gran, lane * Hd + row, epoch, __float_as_uint(lane == 0 ? out3[0] : lane == 1 ? out3[1] : out3[2]));
+    if (w == 0) {
+        const gu64* g64 = (const gu64*)gran;
+        const int nparts = c == c_last ? 3 : 1;          // q for everyone; k, v for the block that holds the newest position
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        for (;;) {
+            u64 v[3];
+            bool ok = true;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                v[p] = (u64)epoch << 32;
+                if (p < nparts) v[p] = __hip_atomic_load(g64 + p * Hd + 64 * h + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(v[p] >> 32) == epoch;
+            }
+            if (__all(ok)) {
+                qg[lane] = round_bf16(__uint_as_float((unsigned)v[0]));
+                kvg[lane] = f2bf(__uint_as_float((unsigned)v[1]));
+                kvg[64 + lane] = f2bf(__uint_as_float((unsigned)v[2]));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                if (lane == 0) __hip_atomic_fetch_or(a.err, QA_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qg[lane] = 0.f; kvg[lane] = 0; kvg[64 + lane] = 0;
+                break;
+            }
+        }
+        if (c == c_last && lane < 32) {                  // the newest position joins the cache (read by later steps' launches)
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(kvg + (lane >> 4) * 64 + (lane & 15) * 4);
+            bf16_t* plane = (lane >> 4) ? a.vcache : a.kcache;
+            *reinterpret_cast<u32x2*>(plane + (size_t)brow * a.kv_row_stride + ((size_t)h * a.max_seq + pos) * 64 + (lane & 15) * 4) = pk;
+        }
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- (4) attention over chunk c (attn_decode.hpp, the launch chain's arithmetic; the newest position from the granules) ----------
+    float qv[G::EPL];
+    {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qg + dsub * G::EPL), q1 = *reinterpret_cast<const f32x4*>(qg + dsub * G::EPL + 4);
+        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+    }
+    const u32x4 ok4 = *reinterpret_cast<const u32x4*>(kvg + dsub * G::EPL), ov4 = *reinterpret_cast<const u32x4*>(kvg + 64 + dsub * G::EPL);
+    const int ovr = c == c_last ? pos : -1;
+    AttnSlotState<bf16_t> ss;
+    ss.m = -1e30f; ss.l = 0.f;
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) ss.o[e] = 0.f;
+    for (int r = 0; r < nround; r += 2) {
+        if (r + 1 < nround) issue(r + 1, kB, vB);
+        attn_round_reduce<bf16_t, true>(ss, qv, kA, vA, start + (r << 7) + woff + slot, end, ovr, ok4, ov4);
+        if (r + 1 < nround) {
+            if (r + 2 < nround) issue(r + 2, kA, vA);
+            attn_round_reduce<bf16_t, true>(ss, qv, kB, vB, start + ((r + 1) << 7) + woff + slot, end, ovr, ok4, ov4);
+        }
+    }
+    const int gs = w * G::PPW + slot;
+    if (dsub == 0) { S.sm[gs] = ss.m; S.sl[gs] = ss.l; }
+#pragma unroll
+    for (int e = 0; e < G::EPL; ++e) S.so[gs][dsub * G::EPL + e] = ss.o[e];
+    __syncthreads();
+    {
+        float M, L, O;
+        attn_fold_quarter<bf16_t>(S, w, lane, M, L, O);
+        if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
+        S.qo[w][lane] = O;
+    }
+    __syncthreads();
+    if (w == 0) {
+        float M, L, O;
+        attn_fold_block<bf16_t>(S, lane, M, L, O);
+        float* ws = a.ws + (size_t)brow * attn_workspace_floats(nheads);
+        float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
+        float* op = ws + (size_t)nheads * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
+        if (lane == 0) { ml[0] = M; ml[1] = L; }
+        op[lane] = O;
+        if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+inline hipError_t launch_qkv_attn(const QkvAttnArgs& a, int heads, int batch, hipStream_t s) {
+    if (a.hidden != 1024 || heads * 64 != a.hidden) return hipErrorInvalidValue;
+    const dim3 grid(ATTN_NCHUNK, heads, batch);
+    if (a.ln_g) hipLaunchKernelGGL((qkv_attn_kernel<PRO_LN>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((qkv_attn_kernel<PRO_PLAIN>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ma
