@@ -991,7 +991,13 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
-        else if (n == "fuse_qkv_attn") { e->opt_fuse_qkv_attn = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "gemv_small_rows") {
+            if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_small_rows must be 0, 1, 2 or 4");
+            gemv_small_rows() = (int)value; e->embtab_ready = false; drop_graphs(e);
+        } else if (n == "gemv_k8_ksplit") {
+            if (value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_k8_ksplit must be 1, 2 or 4");
+            gemv_k8_ksplit() = (int)value; drop_graphs(e);
+        } else if (n == "fuse_qkv_attn") { e->opt_fuse_qkv_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_impl") {
             if (value != 0 && value != 1) throw MaError(MA_ERR_INVALID, "decode_impl must be 0 (launch chain) or 1 (persistent step)");
             e->opt_decode_impl = (int)value;

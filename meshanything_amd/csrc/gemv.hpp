@@ -309,6 +309,13 @@ struct GemvShape { int ksplit, lpl, rpw; };
 // rows per wave for the big matrices (engine option "gemv_rpw"): 1 = most blocks ... 4 = a quarter of the blocks / input copies
 // (default 4: measured 1.4 % (2 vs 1) + 0.5 % (4 vs 2) faster per decode step, profiles/r01_ab_rows_per_wave.txt)
 inline int& gemv_rpw_big() { static int v = 4; return v; }
+// N <= 2048, K = 2 pieces (out_proj, embed): 0 = two waves split K, one row per group (512 blocks at N = 1024);
+// r > 0 = one wave per r whole rows (4 r rows per block: fewer blocks repeat the prologue -- out_proj's merges 67 KB of partials).
+// Default 1 (256 blocks): decode step 519.6 -> 491.7 us at kv 300 (profiles/r02_ab_oproj_block_shape.txt)
+inline int& gemv_small_rows() { static int v = 1; return v; }
+// K = 8 pieces (fc2): waves that split K (4 = 1024 blocks at N = 1024, each staging the 16 KB input; 2; 1 = one wave per row, 256 blocks).
+// Default 1: 494.2 -> 483.0 us (profiles/r02_ab_fc2_block_shape.txt)
+inline int& gemv_k8_ksplit() { static int v = 1; return v; }
 
 template <typename WT>
 inline GemvShape gemv_shape(int N, int K) {
@@ -319,9 +326,9 @@ inline GemvShape gemv_shape(int N, int K) {
     switch (nc) {
         case 1: return {1, 1, rpw > 2 ? 2 : rpw};
         // > 1024 blocks do not fit the chip at once (8195 lm_head rows: 2049 blocks start over 2.9 us): two rows per wave
-        case 2: return N <= 2048 ? GemvShape{2, 1, 1} : GemvShape{1, 2, N > 4096 ? (rpw > 2 ? rpw : 2) : rpw};
+        case 2: return N <= 2048 ? (gemv_small_rows() > 0 ? GemvShape{1, 2, gemv_small_rows()} : GemvShape{2, 1, 1}) : GemvShape{1, 2, N > 4096 ? (rpw > 2 ? rpw : 2) : rpw};
         case 4: return {2, 2, N > 4096 ? 2 : (rpw > 2 ? 2 : rpw)};
-        case 8: return {4, 2, 1};
+        case 8: return gemv_k8_ksplit() == 1 ? GemvShape{1, 8, 1} : gemv_k8_ksplit() == 2 ? GemvShape{2, 4, 1} : GemvShape{4, 2, 1};
         case 16: return {4, 4, 1};
         default: return {1, 0, 1};
     }
@@ -351,7 +358,7 @@ inline hipError_t launch_gemv(const GemvArgs& a, hipStream_t s, int batch = 1) {
     const dim3 grid((a.N + rpb - 1) / rpb, batch);
 #define MA_GEMV_CASE(KS, LP, RW) if (g.ksplit == KS && g.lpl == LP && g.rpw == RW) { launch_gemv_pro<WT, KS, LP, RW>(a, pro, grid, s); return hipGetLastError(); }
     MA_GEMV_CASE(1, 1, 1) MA_GEMV_CASE(1, 1, 2) MA_GEMV_CASE(2, 1, 1) MA_GEMV_CASE(1, 2, 1) MA_GEMV_CASE(1, 2, 2) MA_GEMV_CASE(1, 2, 4) MA_GEMV_CASE(2, 2, 1) MA_GEMV_CASE(2, 2, 2)
-    MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)
+    MA_GEMV_CASE(4, 2, 1) MA_GEMV_CASE(2, 4, 1) MA_GEMV_CASE(1, 8, 1) MA_GEMV_CASE(4, 4, 1) MA_GEMV_CASE(1, 0, 1)
 #undef MA_GEMV_CASE
     return hipErrorInvalidValue;
 }

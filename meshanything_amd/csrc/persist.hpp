@@ -522,7 +522,7 @@ __device__ __forceinline__ void ps_compute(const PersistArgs& a, char* smem, uns
                 ++need_g;                                      // the partials' gather is consumed by wave 0 only
             }
         }
-        // ---- y1 = resid + Wo a + bo, row rn (KSPLIT = 2 shape: one reduction per 512-element piece) ----------------------------
+        // ---- y1 = resid + Wo a + bo, row rn (gemv shape {1, 2, 1}: both 512-element pieces in one chain, one reduction) --------------
         {
             const float bo = PS_G(w.o_b)[rn];
             PS_WAIT_G();
@@ -530,17 +530,17 @@ __device__ __forceinline__ void ps_compute(const PersistArgs& a, char* smem, uns
             PS_WAIT_U(ubase + 3);
             tr.stamp(lane);
             const char* row = ring(ubase + 3) + cw * 2048;
-            float t[2];
+            float acc = 0.f;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 float xa[8];
                 ps_unpack8(*reinterpret_cast<const u32x4*>(smem + PL_XB + (p * 64 + lane) * 16), xa);
-                t[p] = wave_sum(ps_piece(row, p, lane, xa, 0.f));
+                acc = ps_piece(row, p, lane, xa, acc);
             }
+            const float t0s = wave_sum(acc);
             ps_bump(ctrl, PC_SIG, lane);
             tr.stamp(lane);
-            float v = 0.f;
-            v += t[0]; v += t[1];
+            float v = t0s;
             v += bo;
             v += resid;
             if (lane == 0) ps_publish(a.gran, PG_Y1 + rn, ep, __float_as_uint(v));
@@ -568,7 +568,7 @@ __device__ __forceinline__ void ps_compute(const PersistArgs& a, char* smem, uns
             ps_bump(ctrl, PC_PUBLISHED, lane);
             tr.stamp(lane);
         }
-        // ---- y2 = h1 + W2 f + b2, row rn (KSPLIT = 4 / LPL = 2 shape: four 1024-element reductions added in order) ----------------
+        // ---- y2 = h1 + W2 f + b2, row rn (gemv shape {1, 8, 1}: the eight 512-element pieces in one chain, one reduction) ------------
         {
             const float b2 = PS_G(w.fc2_b)[rn];
             PS_WAIT_G();
@@ -576,18 +576,14 @@ __device__ __forceinline__ void ps_compute(const PersistArgs& a, char* smem, uns
             PS_WAIT_U(ubase + 8 + cw);
             tr.stamp(lane);
             const char* row = ring(ubase + 8 + cw);
-            float v = 0.f;
+            float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float xa[8];
-                    ps_unpack8(*reinterpret_cast<const u32x4*>(smem + PL_XB + ((2 * k + i) * 64 + lane) * 16), xa);
-                    acc = ps_piece(row, 2 * k + i, lane, xa, acc);
-                }
-                v += wave_sum(acc);
+            for (int i = 0; i < 8; ++i) {
+                float xa[8];
+                ps_unpack8(*reinterpret_cast<const u32x4*>(smem + PL_XB + (i * 64 + lane) * 16), xa);
+                acc = ps_piece(row, i, lane, xa, acc);
             }
+            float v = wave_sum(acc);
             ps_bump(ctrl, PC_SIG, lane);
             tr.stamp(lane);
             v += b2;
