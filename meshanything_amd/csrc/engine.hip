@@ -28,6 +28,7 @@
 #include "gemm_tile.hpp"
 #include "gemv.hpp"
 #include "misc.hpp"
+#include "oproj_fc1.hpp"
 #include "persist.hpp"
 #include "qkv_attn.hpp"
 #include "state.hpp"
@@ -106,6 +107,8 @@ struct ma_engine {
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
     int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
+    int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
+    u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
     unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
     int opt_decode_impl = 0;         // 0: chain of launches; 1: one persistent launch per step (when eligible)
     int n_cus = 0;
@@ -417,6 +420,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     gemm_dec(e, s, g, tm);
 }
 
+bool fuse_oproj_fc1(ma_engine* e) { return e->opt_fuse_oproj_fc1 && e->bf16 && e->cfg.hidden == 1024 && e->cfg.ffn == 4096 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
 bool fuse_qkv_attn(ma_engine* e) { return e->opt_fuse_qkv_attn && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
 
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
@@ -457,6 +461,19 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
     }
     }
+    if (fuse_oproj_fc1(e)) {
+        // y1 = h + Wo a + bo; h1 = LN1(y1); f = relu(W1 h1 + b1) in one launch: y1 is all-gathered inside it (oproj_fc1.hpp)
+        OprojFc1Args a{};
+        a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b;
+        a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.attn_ws = part; a.heads = c.heads; a.res = resid; a.h1_out = h1; a.ffn_out = ffn;
+        a.st = e->d_st + r0; a.layer = l; a.gran = e->d_y1_gran + r0 * H; a.err = e->d_chain_err;
+        a.res_stride = H; a.h1_stride = H; a.ffn_stride = c.ffn;
+        a.trace = tm.trace_slot(3, H / 4);
+        if (tm.on(0)) {
+            hipError_t r = launch_oproj_fc1(a, H, c.ffn, B, s);
+            if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("oproj_fc1 launch failed: ") + hipGetErrorString(r));
+        }
+    } else {
     {   // y1 = h + Wo a + bo  (LayerNorm deferred to the consumer's prologue)
         GemvArgs a = gemv_base(e, rw);
         // the attention output is never materialised: this GEMV's prologue merges the split-KV partials
@@ -471,6 +488,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         a.y = ffn; a.y_stride = c.ffn; a.N = c.ffn; a.K = H; a.act = ACT_RELU;
         a.trace = tm.trace_slot(4, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
+    }
     }
     {   // y2 = h1 + W2 f + b2
         GemvArgs a = gemv_base(e, rw);
@@ -550,12 +568,12 @@ void check_persist_error(ma_engine* e, hipStream_t s) {
 
 // the fused q/k/v + attention launch reports an expired (bounded) granule sweep through a device word
 void check_chain_error(ma_engine* e, hipStream_t s) {
-    if (!fuse_qkv_attn(e)) return;
+    if (!fuse_qkv_attn(e) && !fuse_oproj_fc1(e)) return;
     HIP_CHECK(hipMemcpyAsync(e->h_chain_err, e->d_chain_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (*e->h_chain_err) {
         HIP_CHECK(hipMemsetAsync(e->d_chain_err, 0, sizeof(unsigned), s));
-        throw MaError(MA_ERR_HIP, "fused q/k/v + attention launch: the in-launch exchange timed out (not all blocks of the grid resident?)");
+        throw MaError(MA_ERR_HIP, "a fused decode launch's in-launch exchange timed out (not all blocks of the grid resident?)");
     }
 }
 
@@ -684,6 +702,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipGetLastError());
     // the fused q/k/v + attention launch tags its exchange with the cache position, which restarts here
     HIP_CHECK(hipMemsetAsync(e->d_qkv_gran, 0, (size_t)e->cfg.max_batch * 3 * e->cfg.hidden * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_y1_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
 }
 
 ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
@@ -851,6 +870,8 @@ void build_engine(ma_engine* e) {
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
     e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(1);
+    e->d_y1_gran = e->dmalloc<u64>(MB * H);
+    HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_chain_err, 0, sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
@@ -998,6 +1019,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
             if (value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_k8_ksplit must be 1, 2 or 4");
             gemv_k8_ksplit() = (int)value; drop_graphs(e);
         } else if (n == "fuse_qkv_attn") { e->opt_fuse_qkv_attn = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "fuse_oproj_fc1") { e->opt_fuse_oproj_fc1 = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_impl") {
             if (value != 0 && value != 1) throw MaError(MA_ERR_INVALID, "decode_impl must be 0 (launch chain) or 1 (persistent step)");
             e->opt_decode_impl = (int)value;

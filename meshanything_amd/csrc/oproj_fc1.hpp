@@ -1,0 +1,187 @@
+// Fused out_proj (+ merge of the split-KV partials) + LayerNorm + fc1 of one layer, batch-1 launch chain (bf16 policy,
+// hidden 1024, ffn 4096).
+//
+// Replaces two launches of the chain ([3p] OPTDecoderLayer: out_proj + residual, self_attn_layer_norm, fc1 + ReLU; reached from
+// shape_opt.py:403-410): both run on 256 blocks already (out_proj: 4 rows per block, fc1: 16 rows per block), so block b of the
+// fused launch does exactly the work of block b of either.  The dependency between them -- every fc1 row needs all 1024 values of
+// y1 = h + Wo a + bo -- is an all-gather of 1024 fp32 values, done inside the launch with tagged granules (MI355X guide, Guideline
+// 16 R2; measured 2.0 us per sweep in the persistent step, profiles/r02_persist_v3_timeline.txt) instead of a kernel boundary +
+// launch ramp + a dependent reload of the vector and its LayerNorm parameters (3.4 us).  Everything that does not depend on the
+// exchange is issued in the first instructions: the attention partials, the out_proj row, the 4 fc1 rows (32 KB per block), biases,
+// LayerNorm parameters.  The arithmetic is gemv_kernel's ({1, 2, 1} and {1, 2, 4} shapes), bit for bit.
+// Epoch = position * 32 + layer + 1 (buffer zeroed when the position restarts); the sweep is bounded (20 ms) and raises the
+// engine's error word instead of hanging; all 256 (x batch) blocks must be resident.
+#pragma once
+#include "attn_decode.hpp"
+#include "common.hpp"
+#include "gemv.hpp"
+#include "persist.hpp"
+#include "state.hpp"
+
+namespace ma {
+
+struct OprojFc1Args {
+    const bf16_t* Wo; const float* bo;                   // [hidden][hidden], [hidden]
+    const bf16_t* W1; const float* b1;                   // [ffn][hidden], [ffn]
+    const float* ln_g; const float* ln_b; float ln_eps;  // self_attn_layer_norm
+    const float* attn_ws; int heads;                     // split-KV partials of this layer (attn_workspace_floats per batch row)
+    const float* res;                                    // the layer input h (fp32, [hidden]): out_proj's residual
+    float* h1_out;                                       // LN1(y1) fp32: fc2's residual
+    float* ffn_out;                                      // relu(fc1) fp32 [ffn]
+    const DecState* st; int layer;
+    u64* gran;                                           // [batch][hidden] granules
+    unsigned* err;
+    int res_stride, h1_stride, ffn_stride;               // per batch row
+    unsigned long long* trace;
+};
+constexpr unsigned OF_ERR_GATHER = 32;
+
+__global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
+    constexpr int KC = 1024;
+    __shared__ __attribute__((aligned(16))) float xl[KC];
+    __shared__ __attribute__((aligned(16))) float yraw[KC];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x, brow = blockIdx.y;
+    if (a.trace && tid == 0) a.trace[b * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    const float* ws = a.attn_ws + (size_t)brow * attn_workspace_floats(a.heads);
+    const unsigned epoch = (unsigned)a.st[brow].pos * 32u + (unsigned)a.layer + 1u;
+
+    // ---- (1) every load that does not depend on the exchange ---------------------------------------------------------------------
+    f32x4 pml[ATTN_NCHUNK / 2], po[ATTN_NCHUNK];
+    {
+        const int k = tid * 4;
+        attn_partials_load(ws, a.heads, k >> 6, k & 63, pml, po);
+    }
+    const int orow = 4 * b + w;                          // out_proj row of this wave
+    u32x4 wo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wo[i] = ld_stream16(a.Wo + (size_t)orow * KC + (i * 64 + lane) * 8);
+    const float e_bo = a.bo[orow], e_res = a.res[(size_t)brow * a.res_stride + orow];
+    u32x4 w1[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w1[j][i] = ld_stream16(a.W1 + (size_t)(16 * b + 4 * w + j) * KC + (i * 64 + lane) * 8);
+    float e_b1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e_b1[j] = a.b1[16 * b + 4 * w + j];
+    f32x4 gv[1], bv[1];
+    gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
+    bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
+    asm volatile("" ::: "memory");
+
+    // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------
+    {
+        f32x4 r = attn_partials_merge(pml, po);
+        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
+    }
+    __syncthreads();
+    float y1;
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k0 = (i * 64 + lane) * 8;
+            float xs[8], wf[8];
+#pragma unroll
+            for (int v = 0; v < 8; v += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
+                xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
+            }
+            unpack16<bf16_t>(wo[i], wf);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
+        }
+        float v = wave_sum(acc);
+        v += e_bo;
+        v += e_res;
+        y1 = v;
+    }
+    if (a.trace && tid == 0) a.trace[b * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- (3) all-gather of y1: one granule per wave out, all 1024 in --------------------------------------------------
+    u64* gran = a.gran + (size_t)brow * KC;
+    if (lane == 0) ps_publish(gran, orow, epoch, __float_as_uint(y1));
+    if (w == 0) {                                        // ONE wave per block sweeps (MI355X guide, polling-cost): 16 granules per lane and pass
+        const gu64* g64 = (const gu64*)gran;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0, pend = 0xffffu;
+        for (;;) {
+            u64 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] = (u64)epoch << 32;
+                if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if ((pend >> k) & 1u) {
+                    const bool ok = (unsigned)(v[k] >> 32) == epoch;
+                    if (ok) yraw[k * 64 + lane] = __uint_as_float((unsigned)v[k]);
+                    if (__all(ok)) pend &= ~(1u << k);
+                }
+            }
+            if (!pend) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) yraw[k * 64 + lane] = 0.f;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[b * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- (4) fc1: gemv_kernel<bf16_t, 1, 2, 4, PRO_LN> on the gathered row ---------------------------------------------------------------
+    {
+        f32x4 xv[1];
+        xv[0] = *reinterpret_cast<const f32x4*>(&yraw[tid * 4]);
+        const float x0 = yraw[0];
+        ln_block_onepass<1>(xv, gv, bv, x0, tid, KC / 4, KC, a.ln_eps, red);
+        if (b == 0) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)brow * a.h1_stride + tid * 4) = xv[0];
+        f32x4 r = xv[0];
+        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
+    }
+    __syncthreads();
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        float xs[8];
+#pragma unroll
+        for (int v = 0; v < 8; v += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
+            xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float wf[8];
+            unpack16<bf16_t>(w1[j][i], wf);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc4[j] = fmaf(wf[v], xs[v], acc4[j]);
+        }
+    }
+    float outv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = wave_sum(acc4[j]);
+        v += e_b1[j];
+        v = fmaxf(v, 0.0f);
+        if (lane == j) outv = v;
+    }
+    if (lane < 4) a.ffn_out[(size_t)brow * a.ffn_stride + 16 * b + 4 * w + lane] = outv;
+    if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+inline hipError_t launch_oproj_fc1(const OprojFc1Args& a, int hidden, int ffn, int batch, hipStream_t s) {
+    if (hidden != 1024 || ffn != 4096 || a.heads * 64 != hidden) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(oproj_fc1_kernel, dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ma

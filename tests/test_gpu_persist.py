@@ -126,15 +126,33 @@ def test_persistent_step_timing_report(eng):
 def test_fused_qkv_attention_launch_is_bitwise_the_two_launches(eng):
     """The launch chain's fused q/k/v + attention launch (csrc/qkv_attn.hpp, default) against the two launches it replaces
     (fuse_qkv_attn = 0): same arithmetic, so bit-identical logits and identical tokens -- batch 1 and a batch of 2 rows."""
-    def run(fuse, prefix, n):
-        eng.set_option("fuse_qkv_attn", fuse)
+    def run(fuse, prefix, n, opt="fuse_qkv_attn"):
+        eng.set_option(opt, fuse)
         try:
             toks, _ = eng.generate(prefix, max_new_tokens=n, suppress_eos=True)
             lg = [eng.read_logits(r).clone() for r in range(prefix.shape[0])]
         finally:
-            eng.set_option("fuse_qkv_attn", 1)
+            eng.set_option(opt, 1)
         torch.cuda.synchronize()
         return toks.cpu(), [x.cpu() for x in lg]
+    # the second fused launch of the chain (csrc/oproj_fc1.hpp): out_proj + LayerNorm + fc1, same criterion
+    for n in (2, 9, 130):
+        t0, g0 = run(0, eng.prefix, n, "fuse_oproj_fc1")
+        t1, g1 = run(1, eng.prefix, n, "fuse_oproj_fc1")
+        assert torch.equal(t0, t1), (n, t0.tolist(), t1.tolist())
+        assert torch.equal(g0[0].view(torch.int32), g1[0].view(torch.int32)), f"oproj+fc1: logits differ after {n} tokens: {float((g0[0] - g1[0]).abs().max()):.3e}"
+    two_ = torch.cat([eng.prefix, eng.prefix.flip(1)])
+    t0, g0 = run(0, two_, 40, "fuse_oproj_fc1")
+    t1, g1 = run(1, two_, 40, "fuse_oproj_fc1")
+    assert torch.equal(t0, t1) and all(torch.equal(g0[r].view(torch.int32), g1[r].view(torch.int32)) for r in range(2))
+    for L in (300, 3858, eng.cfg.max_seq - 80):
+        row = {}
+        for fuse in (0, 1):
+            eng.set_option("fuse_oproj_fc1", fuse)
+            eng.profile_decode(L, 2)
+            row[fuse] = eng.profile_decode(L, 16)["step_ms_graph"] * 1e3
+        eng.set_option("fuse_oproj_fc1", 1)
+        print(f"[fused oproj+fc1 A/B] kv_len {L:5d}: two launches {row[0]:7.1f} us/step | fused {row[1]:7.1f} us/step | ratio {row[1] / row[0]:.3f}")
     for n in (2, 9, 130):
         t0, g0 = run(0, eng.prefix, n)
         t1, g1 = run(1, eng.prefix, n)
