@@ -235,32 +235,46 @@ def main():
         mid = cfg.cond_length + cfg.max_new_tokens // 2
         eng.set_option("profile_batch", args.batch)
         prof = eng.profile_decode(mid, args.profile_steps)
-        wbytes, launches = gemv_bytes_per_step(cfg, esz)
-        n_l = prof["launches"]["gemv"]
-        launches = n_l // args.profile_steps          # 98 GEMVs at batch 1; 98 skinny GEMMs + 73 row prologues on the batched MFMA path
-        avg_ms = prof["ms"]["gemv"] / max(1, n_l)
-        bytes_per_launch = wbytes / launches
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        wbytes, _ = gemv_bytes_per_step(cfg, esz)
+        kvbytes = args.batch * kv_bytes_per_step(cfg, mid, esz)
+        mfma_path = args.batch >= 4 and args.dtype == "bf16"
+        fused_qkv = bool(eng.get_option("fuse_qkv_attn")) and not mfma_path
+        fused_o1 = bool(eng.get_option("fuse_oproj_fc1")) and not mfma_path
+        qkv_w = cfg.layers * 3 * cfg.hidden * cfg.hidden * esz
+        # the launches of a decode step fall in two classes (ma_profile_decode times each class alone, HIP events on the launch
+        # stream around `profile_steps` steps; elapsed / launches = average launch duration, boundary to the next launch included --
+        # what a rocprofv3 kernel trace of the same command reports, profiles/):
+        #   weights : every launch that streams weight matrices only (gemv_kernel, oproj_fc1_kernel; batched: gemm_dec + prologues)
+        #   cache   : the launches that stream the KV cache (attn_decode_kernel, or qkv_attn_kernel = q/k/v weights + cache)
+        classes = {}
+        for key, name, byts in (("gemv", "weights", wbytes - (qkv_w if fused_qkv else 0)), ("attn_decode", "cache", kvbytes + (qkv_w if fused_qkv else 0))):
+            n_l = prof["launches"][key]
+            per_step = n_l // args.profile_steps
+            ms = prof["ms"][key]
+            classes[name] = {"launches_per_step": per_step, "launches_timed": n_l, "avg_launch_us": round(ms / max(1, n_l) * 1e3, 3),
+                             "bytes_per_launch": int(byts / max(1, per_step)), "GBps": round(byts / max(1, per_step) / (ms / max(1, n_l) * 1e-3) / 1e9, 1),
+                             "us_per_step": round(ms / args.profile_steps * 1e3, 1)}
+        kern = {"weights": ("gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream)" if mfma_path else
+                            ("oproj_fc1_kernel + gemv_kernel (fc2, embed, lm_head)" if fused_o1 else "gemv_kernel") + " -- the launches that stream weight matrices only"),
+                "cache": ("qkv_attn_kernel (q/k/v projection + split-KV attention: q/k/v weights + the KV cache)" if fused_qkv else "attn_decode_kernel (KV cache)")}
+        dom = max(classes, key=lambda k: classes[k]["us_per_step"])          # the class the step spends most of its time in
+        dc = classes[dom]
         step_ms = prof["step_ms_graph"] or prof["step_ms_eager"]
-        step_bytes = wbytes + args.batch * kv_bytes_per_step(cfg, mid, esz)
-        attn_ms = prof["ms"]["attn_decode"] / max(1, prof["launches"]["attn_decode"])
-        # HBM bytes per GEMV launch from the PMC counters (collected by scripts/gpu_pmc.sh in separate rocprofv3 --pmc passes and
+        step_bytes = wbytes + kvbytes
+        # HBM bytes per launch of the dominant class from the PMC counters (scripts/gpu_pmc_r2.sh: separate rocprofv3 --pmc passes,
         # corrected as the MI355X guide prescribes; committed under profiles/): None when no such file is present
         traffic = None
         import glob
-        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_gemv_traffic.json"))):
+        for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r02_pmc_decode_traffic.json"))):
             if args.batch == 1 and args.dtype == "bf16" and args.faces == 800:
-                traffic = int(json.load(open(f))["hbm_bytes_per_launch"])
-        roofline = {"bound": "hbm", "kernel": f"gemv_kernel (decode weight stream, {launches} launches per step)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": n_l,
+                traffic = json.load(open(f)).get("hbm_bytes_per_launch", {}).get(dom)
+        roofline = {"bound": "hbm", "kernel": f"{kern[dom]}, {dc['launches_per_step']} launches per step", "achieved": dc["GBps"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dc["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes_per_launch": dc["bytes_per_launch"], "avg_launch_us": dc["avg_launch_us"], "launches_timed": dc["launches_timed"],
+                    "kv_len": mid, "classes": {k: dict(v, kernel=kern[k]) for k, v in classes.items()},
                     "decode_step_ms_graph": round(prof["step_ms_graph"], 4), "decode_step_ms_eager": round(prof["step_ms_eager"], 4),
                     "decode_step_GBps_at_mid_context": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
-                    "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "attn_decode": {"kv_len": mid, "avg_launch_us": round(attn_ms * 1e3, 3),
-                                    "GBps": round(args.batch * kv_bytes_per_step(cfg, mid, esz) / cfg.layers / (attn_ms * 1e-3) / 1e9, 1)}}
-        if args.batch > 1 and args.dtype == "bf16" and args.batch >= 4:
-            roofline["kernel"] = "gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream: 98 skinny GEMMs + 73 prologues per step)"
+                    "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))

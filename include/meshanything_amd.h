@@ -114,6 +114,9 @@ MA_API int  ma_engine_create(ma_engine **out, const ma_config *cfg, int device);
 MA_API void ma_engine_destroy(ma_engine *e);
 /* integer options (debug / A-B switches); see DESIGN.md.  Unknown names -> MA_ERR_INVALID. */
 MA_API int  ma_engine_set_option(ma_engine *e, const char *name, int64_t value);
+/* reads an option back as the engine will apply it (e.g. "fuse_qkv_attn" is 1 only if the option is on AND the configuration is
+ * eligible); names: fuse_qkv_attn, fuse_oproj_fc1, decode_impl, persist_available, use_graph, dense_rows, mfma_min_batch */
+MA_API int  ma_engine_get_option(ma_engine *e, const char *name, int64_t *value);
 
 /* ---- weights ------------------------------------------------------------------------------------------ */
 /* replaces: safe_open(...) + load_state_dict(strict=True), main.py:99-104.  May be called repeatedly with

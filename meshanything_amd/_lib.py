@@ -48,6 +48,7 @@ SIGNATURES = {
     "ma_engine_create": (_I, [C.POINTER(_P), C.POINTER(CMAConfig), _I]),
     "ma_engine_destroy": (None, [_P]),
     "ma_engine_set_option": (_I, [_P, C.c_char_p, C.c_int64]),
+    "ma_engine_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "ma_engine_load_weights": (_I, [_P, C.POINTER(TensorDesc), _I]),
     "ma_engine_finalize_weights": (_I, [_P]),
     "ma_engine_arena": (_I, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -1033,6 +1033,21 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
     });
 }
 
+int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
+    if (!e || !name || !value) return MA_ERR_INVALID;
+    return guarded(e, [&] {
+        const std::string n = name;
+        if (n == "fuse_qkv_attn") *value = fuse_qkv_attn(e) ? 1 : 0;                 // effective values: option AND eligibility
+        else if (n == "fuse_oproj_fc1") *value = fuse_oproj_fc1(e) ? 1 : 0;
+        else if (n == "decode_impl") *value = e->opt_decode_impl;
+        else if (n == "persist_available") *value = e->persist_shape ? 1 : 0;
+        else if (n == "use_graph") *value = e->cfg.use_graph;
+        else if (n == "dense_rows") *value = e->dense_rows;
+        else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
+        else throw MaError(MA_ERR_INVALID, "unknown option " + n);
+    });
+}
+
 int ma_engine_load_weights(ma_engine* e, const ma_tensor_desc* tensors, int n) {
     if (!e || (!tensors && n > 0)) return MA_ERR_INVALID;
     return guarded(e, [&] {
@@ -1448,6 +1463,12 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
             for (int i = 0; i < steps; ++i) {
                 if (only_cls == -2) HIP_CHECK(hipGraphLaunch(e->gexec.at(gkey), s));
                 else enqueue_decode_step(e, s, -1, tm, Rows{0, B}, impl);
+                if (only_cls >= 0 && only_cls != 3) {
+                    // without the pick launch the state would not advance, and the fused launches tag their in-launch exchanges
+                    // with the cache position: move it by hand (one tiny launch per step, charged to the class being timed)
+                    hipLaunchKernelGGL(set_pos_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, e->d_st, kv_len - e->T + i + 1, kv_len + i, 5, B);
+                    HIP_CHECK(hipGetLastError());
+                }
             }
             HIP_CHECK(hipEventRecord(b, s));
             HIP_CHECK(hipStreamSynchronize(s));

@@ -56,6 +56,11 @@ class Engine:
     def set_option(self, name: str, value: int) -> None:
         self._check(self.lib.ma_engine_set_option(self.h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        self._check(self.lib.ma_engine_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     # ---------------------------------------------------------------- weights (main.py:99-104)
     @staticmethod
     def _desc(name: str, arr) -> Tuple[_lib.TensorDesc, object]:
