@@ -239,10 +239,12 @@ def synthetic_state_dict(cfg: MAConfig, seed: int = 1234, include_unused: bool =
     return OrderedDict(synthetic_items(cfg, seed, include_unused, bert_fused, init))
 
 
-def load_safetensors_items(path: str) -> Iterator[Tuple[str, np.ndarray]]:
-    """Iterate the tensors of the released checkpoint (`MeshAnything_350m.pth` is a safetensors file, main.py:95-104)."""
+def load_safetensors_items(path: str) -> Iterator[Tuple[str, object]]:
+    """Iterate the tensors of the released checkpoint (`MeshAnything_350m.pth` is a safetensors file, main.py:95-104).
+    Tensors come back as torch tensors in their STORED dtype (numpy has no bfloat16, so the numpy reader rejects bf16 files);
+    the engine's packer takes fp32 / fp16 / bf16 storage as is (Engine._desc)."""
     from safetensors import safe_open
-    with safe_open(path, framework="np") as f:
+    with safe_open(path, framework="pt", device="cpu") as f:
         for k in f.keys():
             yield k, f.get_tensor(k)
 

@@ -89,10 +89,17 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
     return faces
 
 
-def write_obj(path: str, verts: np.ndarray, faces: np.ndarray) -> None:
+FACE_COLOR = (255, 165, 0)                                   # main.py:170 (`brown_color`, alpha 255)
+
+
+def write_obj(path: str, verts: np.ndarray, faces: np.ndarray, color=FACE_COLOR) -> None:
+    """main.py:170-174 sets one colour on every face and calls `export(.obj)`.  The OBJ format has no per-face colour; trimesh's
+    OBJ writer turns face colours into vertex colours and appends them to the vertex lines (`v x y z r g b`, components in
+    0..1) -- with one colour for all faces every vertex gets that colour.  `color=None` writes plain `v x y z` lines."""
+    tail = "" if color is None else " " + " ".join(f"{c / 255.0:.8f}" for c in color[:3])
     with open(path, "w") as f:
         f.write("# MeshAnything (meshanything_amd)\n")
         for v in verts:
-            f.write(f"v {v[0]:.8f} {v[1]:.8f} {v[2]:.8f}\n")
+            f.write(f"v {v[0]:.8f} {v[1]:.8f} {v[2]:.8f}{tail}\n")
         for t in faces:
             f.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")

@@ -24,6 +24,21 @@ def test_safetensors_file_packs_like_memory(tmp_path, policy):
     assert set(keys) == set(state_dict_spec(cfg, include_unused=True))
 
 
+def test_bf16_stored_safetensors_file(tmp_path):
+    """A checkpoint saved in bfloat16 (what `model.to(torch.bfloat16).save_pretrained` writes) loads from disk: numpy has no
+    bf16, so the file is read through torch and the packer gets the 16-bit payload."""
+    cfg = MAConfig.tiny(dtype=DTYPE_BF16)
+    sd = synthetic_state_dict(cfg)
+    as_bf16 = {k: torch.from_numpy(v).to(torch.bfloat16) for k, v in sd.items()}
+    path = tmp_path / "bf16.safetensors"
+    safetensors_torch.save_file(as_bf16, str(path))
+    items = list(load_safetensors_items(str(path)))
+    assert all(t.dtype == torch.bfloat16 for _, t in items)
+    got = dp.pack_host_arena(cfg, items)
+    ref = dp.pack_host_arena(cfg, ((k, bf16_round(v)) for k, v in sd.items()))   # same values, stored as fp32
+    assert np.array_equal(got, ref)
+
+
 def test_half_precision_checkpoints_and_fused_bert_names(tmp_path):
     cfg = MAConfig.tiny(dtype=DTYPE_BF16)
     sd = synthetic_state_dict(cfg)

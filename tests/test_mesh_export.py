@@ -18,6 +18,11 @@ def test_faces_from_coords_merges_and_dedups(tmp_path):
     write_obj(str(p), v, f)
     lines = p.read_text().splitlines()
     assert sum(l.startswith("v ") for l in lines) == 4 and sum(l.startswith("f ") for l in lines) == 3
+    # main.py:170-173: one colour (255, 165, 0) on every face -> carried as vertex colours on the `v` lines
+    vl = [l.split() for l in lines if l.startswith("v ")]
+    assert all(len(t) == 7 and [float(x) for x in t[4:]] == [1.0, round(165 / 255, 8), 0.0] for t in vl)
+    write_obj(str(p), v, f, color=None)
+    assert all(len(l.split()) == 4 for l in p.read_text().splitlines() if l.startswith("v "))
     v0, f0 = faces_from_coords(np.full((4, 3, 3), np.nan, np.float32))
     assert v0.shape == (0, 3) and f0.shape == (0, 3)
 
