@@ -293,4 +293,97 @@ inline hipError_t launch_attn_decode(const float* q, const void* kc, const void*
     return hipGetLastError();
 }
 
+// FINAL form for batches that fill the chip on (row, head) pairs alone (>= 16 rows x 16 heads = 256 blocks): one block per
+// (row, head), its 4 waves split ALL cached positions of the head (rounds of 128), the block-level merge finishes the softmax
+// and the normalised output goes straight to the out_proj GEMM's bf16 activation buffer -- no partials in HBM, no merge launch
+// ([3p] flash_attn_func with q_len 1, one call per layer).  Same per-slot arithmetic (attn_round_reduce) and block merge
+// (attn_fold_quarter / attn_fold_block) as the split form; only the grouping of positions into partial states differs.
+template <typename KT>
+__global__ __launch_bounds__(256) void attn_decode_final_kernel(const float* __restrict__ q, const KT* __restrict__ kc, const KT* __restrict__ vc,
+                                                                int max_seq, const DecState* st, int len_override, int round_q,
+                                                                bf16_t* __restrict__ out, int out_stride, int q_stride, size_t kv_row_stride) {
+    using G = AttnGeom<KT>;
+    constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, U = G::U;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int h = blockIdx.x, brow = blockIdx.y;
+    const int slot = lane / LPP, dsub = lane % LPP;
+    q += (size_t)brow * q_stride;
+    kc += (size_t)brow * kv_row_stride;
+    vc += (size_t)brow * kv_row_stride;
+    float qv[EPL];
+    {
+        const float* qp = q + h * 64 + dsub * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(qp + e);
+            qv[e] = t.x; qv[e + 1] = t.y; qv[e + 2] = t.z; qv[e + 3] = t.w;
+        }
+    }
+    const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
+    const int nround = (max(end, 0) + 127) >> 7;
+    const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
+    const KT* vh = vc + (size_t)h * max_seq * 64 + dsub * EPL;
+    u32x4 kA[U], vA[U], kB[U], vB[U];
+    auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
+        const int base = (r << 7) + w * 32 + slot;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * PPW;
+            kr[u] = ld_stream16(kh + (size_t)(p < end ? p : 0) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = base + u * PPW;
+            vr[u] = ld_stream16(vh + (size_t)(p < end ? p : 0) * 64);
+        }
+    };
+    AttnSlotState<KT> ss;
+    ss.m = -1e30f; ss.l = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
+    const u32x4 none = {0u, 0u, 0u, 0u};
+    auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
+        attn_round_reduce<KT, false>(ss, qv, kr, vr, (r << 7) + w * 32 + slot, end, -1, none, none);
+    };
+    if (round_q) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qv[e] = round_bf16(qv[e]);
+    }
+    if (nround > 0) issue(0, kA, vA);
+    for (int r = 0; r < nround; r += 2) {
+        if (r + 1 < nround) issue(r + 1, kB, vB);
+        reduce(r, kA, vA);
+        if (r + 1 < nround) {
+            if (r + 2 < nround) issue(r + 2, kA, vA);
+            reduce(r + 1, kB, vB);
+        }
+    }
+    __shared__ AttnMergeLds<KT> S;
+    const int gs = w * PPW + slot;
+    if (dsub == 0) { S.sm[gs] = ss.m; S.sl[gs] = ss.l; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) S.so[gs][dsub * EPL + e] = ss.o[e];
+    __syncthreads();
+    {
+        float M, L, O;
+        attn_fold_quarter<KT>(S, w, lane, M, L, O);
+        if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
+        S.qo[w][lane] = O;
+    }
+    __syncthreads();
+    if (w == 0) {
+        float M, L, O;
+        attn_fold_block<KT>(S, lane, M, L, O);
+        out[(size_t)brow * out_stride + h * 64 + lane] = f2bf(O * (1.0f / L));     // position 0 always exists: L > 0
+    }
+}
+
+template <typename KT>
+inline hipError_t launch_attn_decode_final(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
+                                           int round_q, bf16_t* out, int out_stride, hipStream_t s, int batch, int q_stride, size_t kv_row_stride) {
+    hipLaunchKernelGGL((attn_decode_final_kernel<KT>), dim3(H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
+                       reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+    return hipGetLastError();
+}
+
 }  // namespace ma

@@ -104,6 +104,8 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
+    int opt_attn_final_min_batch = 16;   // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
+    int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
     int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
@@ -381,11 +383,19 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
             gemm_dec(e, s, a, tm);
         }
-        if (tm.on(1)) {
-            hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems, true);
-            if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+        if (B >= e->opt_attn_final_min_batch) {
+            // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
+            if (tm.on(1)) {
+                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems);
+                if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode_final launch failed: ") + hipGetErrorString(r));
+            }
+        } else {
+            if (tm.on(1)) {
+                hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems, e->opt_attn_rowwave != 0);
+                if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
+            }
+            rows_prologue(e, s, PRO_ATTN, rw, ProIn{}, nullptr, nullptr, nullptr, tm);
         }
-        rows_prologue(e, s, PRO_ATTN, rw, ProIn{}, nullptr, nullptr, nullptr, tm);
         {   // y1 = resid + Wo a + bo
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.xb = xb; a.xb_stride = H; a.N = H; a.K = H; a.B = B; a.ksplit = ks_o; a.y_stride = H;
@@ -1012,6 +1022,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "use_graph") e->cfg.use_graph = (int)value;
         else if (n == "profile_batch") e->opt_profile_batch = (int)value;
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
+        else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
+        else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
         else if (n == "gemv_small_rows") {
             if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_small_rows must be 0, 1, 2 or 4");
             gemv_small_rows() = (int)value; e->embtab_ready = false; drop_graphs(e);
@@ -1044,6 +1056,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "use_graph") *value = e->cfg.use_graph;
         else if (n == "dense_rows") *value = e->dense_rows;
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
+        else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
+        else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
 }
@@ -1366,6 +1380,18 @@ int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, cons
         // in the engine the merge of the split partials is the prologue of the out_proj GEMV; here it runs on its own
         hipLaunchKernelGGL(attn_merge_kernel, dim3(ceil_div(H * 16, 256)), dim3(256), 0, s, ws, H, out);
         HIP_CHECK(hipGetLastError());
+    });
+}
+
+// batched single-query attention, final form (attn_decode_final_kernel): B rows, each its own cache plane, all of length `len`;
+// out = bf16 [B][H * 64]
+int ma_op_decode_attention_rows(const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int B, size_t kv_row_stride,
+                                void* out, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!q || !kcache || !vcache || !out || H < 1 || B < 1 || len < 1 || len > max_seq || kv_row_stride < (size_t)H * max_seq * 64)
+            throw MaError(MA_ERR_INVALID, "ma_op_decode_attention_rows: bad arguments");
+        HIP_CHECK(launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64,
+                                                   reinterpret_cast<hipStream_t>(stream), B, H * 64, kv_row_stride));
     });
 }
 

@@ -205,6 +205,35 @@ def test_decode_attention(lib, kvdtype, length, max_seq, H):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("B,length,H", [(16, 1, 16), (16, 257, 16), (17, 130, 2), (40, 1000, 16), (64, 1500, 16)])
+def test_decode_attention_rows(lib, B, length, H):
+    """Final-form batched decode attention (>= 16 rows: one block per (row, head), normalised bf16 output, no merge launch):
+    every row against the fp32 softmax reference on the same bf16-rounded q / K / V; bit-stable across launches; rows of the
+    cache beyond `length` hold NaN and must not be touched."""
+    g = torch.Generator().manual_seed(B * 7 + length)
+    max_seq = length + 3
+    q = torch.randn(B, H * 64, generator=g)
+    k = torch.randn(B, H, max_seq, 64, generator=g)
+    v = torch.randn(B, H, max_seq, 64, generator=g)
+    k[:, :, length:] = float("nan"); v[:, :, length:] = float("nan")
+    kd, vd = k.to(torch.bfloat16).cuda().contiguous(), v.to(torch.bfloat16).cuda().contiguous()
+    qd = q.cuda()
+    outs = []
+    for it in range(2):
+        out = torch.full((B, H * 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+        _chk(lib, lib.ma_op_decode_attention_rows(_p(qd), _p(kd), _p(vd), H, max_seq, length, B, H * max_seq * 64, _p(out), _stream()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
+    qb = q.to(torch.bfloat16).float().reshape(B, H, 64)
+    kf, vf = kd.cpu().float()[:, :, :length], vd.cpu().float()[:, :, :length]
+    p = torch.softmax(torch.einsum("bhd,bhsd->bhs", qb.double(), kf.double()) * 0.125, dim=-1)
+    ref = torch.einsum("bhs,bhsd->bhd", p, vf.double()).reshape(B, H * 64).float()
+    # output is rounded to bf16 (2^-9 relative); values are O(1)
+    assert float((outs[0].float() - ref).abs().max()) < 1.5e-2
+    assert float((outs[0].float() - ref.to(torch.bfloat16).float()).abs().mean()) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------- batched decode step kernels
 @pytest.mark.parametrize("B", [4, 16, 17, 40, 64])
 @pytest.mark.parametrize("N,K,ksplit,act", [(3072, 1024, 1, 0), (4096, 1024, 1, 1), (1024, 1024, 4, 0), (1024, 4096, 4, 0), (1024, 4096, 1, 0),

@@ -221,6 +221,15 @@ def test_large_batches_all_mfma_tile_counts(B):
     env.engine.set_option("mfma_min_batch", 4)
     same = int((ref == toks).all(dim=1).sum())
     assert same >= int(0.75 * B), f"only {same}/{B} rows equal the GEMV path"
+    # >= 16 rows: the attention launch writes the finished output (one block per (row, head)); below, split-KV partials + a
+    # merge launch.  Same arithmetic per position, different grouping of the partial softmax states.
+    assert env.engine.get_option("attn_final_min_batch") == 16
+    env.engine.set_option("attn_final_min_batch", 1000)
+    split, split_len = env.engine.generate(prefix.cuda(), suppress_eos=True)
+    env.engine.set_option("attn_final_min_batch", 16)
+    _check_greedy(env, prefix, split, split_len, suppress_eos=True)
+    same = int((split == toks).all(dim=1).sum())
+    assert same >= int(0.75 * B), f"only {same}/{B} rows equal between the final and the split attention forms"
     out = env.engine.forward(x.cuda(), suppress_eos=True)           # encode + batched prefill + decode + detokenize for the whole batch
     assert out["coords"].shape == (B, cfg.n_max_faces, 3, 3) and out["tokens"].shape == toks.shape
     # (its prefix comes from the engine's own bf16 encoder, not the oracle's: near-tie rows may differ from `toks`)
