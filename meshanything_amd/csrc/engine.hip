@@ -105,6 +105,7 @@ struct ma_engine {
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     int opt_attn_final_min_batch = 16;   // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
+    int opt_gemm_xcd_swizzle = 1;    // dense GEMM: hand the tiles out XCD-aware (gemm_tile.hpp)
     int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
     int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
@@ -163,7 +164,7 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         GemmTArgs t{};
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
-        t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map;
+        t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
         r = launch_gemm_tile(t, s);
     } else {
         GemmArgs g{};
@@ -1024,6 +1025,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
+        else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
+        else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
         else if (n == "gemv_small_rows") {
             if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_small_rows must be 0, 1, 2 or 4");
             gemv_small_rows() = (int)value; e->embtab_ready = false; drop_graphs(e);
@@ -1058,6 +1061,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
+        else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
+        else if (n == "gemm_variant") *value = gemm_tile_variant();
         else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
 }
@@ -1327,6 +1332,7 @@ int ma_op_gemm(int wdtype, int impl, const float* A, int lda, const void* W, con
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&Ab), (size_t)M * K * sizeof(bf16_t)));
             hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(ceil_div(M * K, 256)), dim3(256), 0, s, A, lda, Ab, K, M, K);
             GemmTArgs t{Ab, K, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, nullptr, 0, M, N, K, act};
+            t.xcd_swizzle = 1;
             r = launch_gemm_tile(t, s);
             (void)hipStreamSynchronize(s);
             (void)hipFree(Ab);
@@ -1343,6 +1349,7 @@ int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
     return guarded(nullptr, [&] {
         if (!A || !W || (!C && !Cb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_bf16: null pointer");
         GemmTArgs t{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, reinterpret_cast<bf16_t*>(Cb), ldcb, M, N, K, act};
+        t.xcd_swizzle = 1;
         hipError_t r = launch_gemm_tile(t, reinterpret_cast<hipStream_t>(stream));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_bf16: ") + hipGetErrorString(r));
     });

@@ -7,10 +7,13 @@
 // Structure (MI355X guide section 5, the 128 x 128 LDS-staged tile with global_load_lds):
 //   * block tile 128 (M) x 128 (N) x 64 (K), 4 waves as 2 x 2, each wave a 64 x 64 sub-tile = 4 x 4 v_mfma_f32_16x16x32_bf16
 //     tiles (16 fp32x4 accumulators); a 64 x 64 x 32 variant serves the small problems (M <= 64, pre_kl N = 64, tiny shapes);
-//   * both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip), two
-//     LDS stages: the loads of K-tile t + 1 fly under the MFMAs of K-tile t, one barrier per K-tile;
+//   * both operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR round trip) into a
+//     ring of NS LDS stages: the loads of K-tiles t + 1 .. t + NS - 1 fly under the MFMAs of K-tile t (s_waitcnt vmcnt(n) lets
+//     the younger tiles stay in flight), one barrier per K-tile.  What bounds the kernel is the bytes in flight per CU against
+//     the ~1.5 us loaded memory latency (dense phases), hence the ring;
 //   * the LDS image is lane-linear (the DMA cannot scatter), so the bank-conflict swizzle is applied to the SOURCE address:
-//     16-byte chunk c of tile row r is fetched into slot c ^ (r & 7) and read back from there by ds_read_b128;
+//     16-byte chunk c of tile row r is fetched into slot c ^ swz(r) and read back from there by ds_read_b128 (swz = r & 7 for
+//     128-byte tile rows, (r >> 1) & 3 for 64-byte rows: conflict-free for the hardware's 16-lane ds_read_b128 groups);
 //   * the W tile is the MFMA A operand and the activation tile the B operand, so a lane ends up with FOUR CONSECUTIVE n of one
 //     output row m: bias / residual / outputs move as 16-byte (fp32) or 8-byte (bf16) vectors;
 //   * epilogue fused: bias, ReLU / GELU(erf), fp32 residual; the result is stored as fp32 (residual stream, LayerNorm input)
@@ -34,6 +37,7 @@ struct GemmTArgs {
     int M, N, K, act;
     int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
     RowMap cmap;                    // output row of logical row m
+    int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
 };
 
 __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
@@ -42,17 +46,33 @@ __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// BM x BN x BK block tile, 4 waves as 2 x 2.  LDS: 2 stages x (BM + BN) rows x BK bf16.
-template <int BM, int BN, int BK>
+template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// BM x BN x BK block tile, 4 waves as 2 x 2.  LDS: NS stages x (BM + BN) rows x BK bf16.
+template <int BM, int BN, int BK, int NS>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
+    auto swz = [](int r) { return CH == 8 ? (r & 7) : ((r >> 1) & 3); };
     constexpr int RPI = 64 / CH;                      // tile rows one DMA instruction covers
     constexpr int ROWB = BK * 2;                      // bytes per tile row
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
     constexpr int TM = BM / 32, TN = BN / 32;         // 16 x 16 MFMA tiles per wave along m / n
     extern __shared__ __attribute__((aligned(16))) char gt_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own L2.  With the plain
+    // (x = N tile, y = M tile) order and 8 N tiles, XCD i would own N-tile column i and stream EVERY activation tile through
+    // its L2: 8 x the activation bytes over the fabric.  Remapped, XCD i owns the i-th eighth of the tile list in (m, n)
+    // order: the N tiles of one M tile run back to back on ONE XCD, so an activation tile crosses the fabric once and the
+    // weight matrix (<= 8 MB) is the operand that is shared through L2 / Infinity Cache.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (g.xcd_swizzle) {
+        const int NT = gridDim.x, tiles = NT * gridDim.y;
+        const int L = blockIdx.y * NT + blockIdx.x;
+        const int xcd = L & 7, i = L >> 3, lo = tiles >> 3, rem = tiles & 7;
+        const int t = xcd * lo + min(xcd, rem) + i;
+        tile_y = t / NT; tile_x = t - tile_y * NT;
+    }
+    const int bm = tile_y * BM, bn = tile_x * BN;
     const unsigned lds0 = (unsigned)(size_t)gt_smem;
 
     // ---- DMA addressing: instruction p of an operand covers tile rows p * RPI .. + RPI - 1; lane -> (row, slot) -----------
@@ -64,14 +84,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
         for (int p = w; p < BM / RPI; p += 4) {
             const int r = p * RPI + drow;
             const int m = min(bm + r, g.M - 1);
-            const bf16_t* src = g.A + (size_t)m * g.lda + k0 + ((dslot ^ (r & (CH - 1))) * 8);
+            const bf16_t* src = g.A + (size_t)m * g.lda + k0 + ((dslot ^ swz(r)) * 8);
             gt_glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)p * 1024u));
         }
 #pragma unroll
         for (int p = w; p < BN / RPI; p += 4) {
             const int r = p * RPI + drow;
             const int n = min(bn + r, g.N - 1);
-            const bf16_t* src = g.W + (size_t)n * g.K + k0 + ((dslot ^ (r & (CH - 1))) * 8);
+            const bf16_t* src = g.W + (size_t)n * g.K + k0 + ((dslot ^ swz(r)) * 8);
             gt_glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)A_BYTES + (unsigned)p * 1024u));
         }
     };
@@ -84,12 +104,17 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
 
     const int fr = lane & 15, kg = lane >> 4;          // fragment row, 8-element k group
     const int nk = g.K / BK;
-    issue(0, 0);
+    constexpr int PF = NS - 1;                         // K-tiles in flight ahead of the one being multiplied
+    constexpr int IPW = (BM / RPI + BN / RPI) / 4;     // DMA instructions per wave and K-tile
+    static_assert((BM / RPI) % 4 == 0 && (BN / RPI) % 4 == 0 && (PF - 1) * IPW < 64, "tile shape");
+#pragma unroll
+    for (int t = 0; t < PF; ++t) if (t < nk) issue(t, t);
+    int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of K-tile kt have landed ...
-        __syncthreads();                                       // ... and everyone's; the other stage is free (its readers are done)
-        if (kt + 1 < nk) issue(kt + 1, stage ^ 1);
+        if (kt + PF <= nk) gt_wait_vm<(PF - 1) * IPW>();       // this wave's pieces of K-tile kt have landed (younger tiles still fly) ...
+        else gt_wait_vm<0>();
+        __syncthreads();                                       // ... and everyone's; the stage read last iteration is free
+        if (kt + PF < nk) issue(kt + PF, stage == 0 ? NS - 1 : stage - 1);
         const char* sa = gt_smem + stage * STAGE;
         const char* sw = sa + A_BYTES;
 #pragma unroll
@@ -98,12 +123,12 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int r = wn * (BN / 2) + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(sw + r * ROWB + (((s * 4 + kg) ^ (r & (CH - 1))) * 16));
+                wf[i] = *reinterpret_cast<const bf16x8_t*>(sw + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int r = wm * (BM / 2) + j * 16 + fr;
-                xf[j] = *reinterpret_cast<const bf16x8_t*>(sa + r * ROWB + (((s * 4 + kg) ^ (r & (CH - 1))) * 16));
+                xf[j] = *reinterpret_cast<const bf16x8_t*>(sa + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
@@ -111,6 +136,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
+        stage = stage + 1 == NS ? 0 : stage + 1;
     }
 
     // ---- epilogue: lane holds n = n0 .. n0 + 3 of row m ------------------------------------------------------------------------
@@ -154,25 +180,41 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     }
 }
 
+// variant knob (engine option gemm_variant; A/B in profiles/): 0 = K-tile 64, 2 stages | 1 = K-tile 32, 4 stages | 2 = K-tile 32, 5 stages |
+// 3 = K-tile 64, 3 stages (one block per CU)
+inline int& gemm_tile_variant() { static int v = 0; return v; }
+
+template <int BM, int BN, int BK, int NS>
+inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
+    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (r != hipSuccess) return r;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(256), LDS, s, g);
+    return hipGetLastError();
+}
+
 // 16-byte DMA sources and vector epilogue accesses need: lda % 8 == 0, K % 32 == 0, ldc / ldr % 4 == 0, ldcb % 4 == 0
 inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
-    static bool attr = false;
-    constexpr int BIG = 2 * (128 + 128) * 64 * 2;      // 64 KiB
-    if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<128, 128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, BIG);
-        if (r != hipSuccess) return r;
-        attr = true;
-    }
     const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160)
-        hipLaunchKernelGGL((gemm_tile_kernel<128, 128, 64>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), BIG, s, g);
-    else if (g.K % 64 == 0 && g.M > 64 && g.N > 32)          // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
-        hipLaunchKernelGGL((gemm_tile_kernel<128, 64, 64>), dim3((g.N + 63) / 64, (g.M + 127) / 128), dim3(256), 2 * (128 + 64) * 64 * 2, s, g);
-    else
-        hipLaunchKernelGGL((gemm_tile_kernel<64, 64, 32>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 2 * (64 + 64) * 32 * 2, s, g);
-    return hipGetLastError();
+    const int v = gemm_tile_variant();
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) {
+        if (v == 1) return gt_launch<128, 128, 32, 4>(g, s);
+        if (v == 2) return gt_launch<128, 128, 32, 5>(g, s);
+        if (v == 3) return gt_launch<128, 128, 64, 3>(g, s);
+        return gt_launch<128, 128, 64, 2>(g, s);
+    }
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 32) {      // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
+        if (v == 1 || v == 2) return gt_launch<128, 64, 32, 5>(g, s);
+        if (v == 3) return gt_launch<128, 64, 64, 3>(g, s);
+        return gt_launch<128, 64, 64, 2>(g, s);
+    }
+    return gt_launch<64, 64, 32, 2>(g, s);
 }
 
 // fp32 -> bf16 rows (kernel-level entry point ma_op_gemm with a bf16 weight and an fp32 activation matrix; small utility elsewhere)

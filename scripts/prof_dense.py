@@ -12,11 +12,17 @@ from meshanything_amd.engine import Engine
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", default="1,8,16,64")
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--options", default="", help="engine options, e.g. gemm_xcd_swizzle=0")
 a = ap.parse_args()
 batches = [int(b) for b in a.batches.split(",")]
 cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=max(batches))
 eng = Engine(cfg)
 eng.load_weights(synthetic_items(cfg))
+for kv in a.options.split(","):
+    if kv:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+        print(f"option {k} = {v}", flush=True)
 PEAK = 2500.0
 GF = {"encode+prefix": 108.5 + 0.8, "prefill": 158.5, "detokenize": 115.6}
 g = torch.Generator().manual_seed(0)
