@@ -211,11 +211,11 @@ MA_API int  ma_op_attention(const float *Q, int q_rs, int q_hs, const float *K, 
 MA_API int  ma_op_decode_attention(int kvdtype, const float *q, const void *kcache, const void *vcache, int H, int max_seq,
                                    int len, float *out, void *workspace, void *stream);
 MA_API size_t ma_decode_attention_workspace_bytes(int H);
-/* the batched decode path's form for >= 16 rows: one block per (row, head) over all `len` cached positions, output already
- * normalised and rounded: out = bf16 [B][H*64].  q fp32 [B][H*64]; row b's cache planes start at b * kv_row_stride elements
+/* the batched decode path's "final" form: one block of `waves` waves (4 | 8 | 16; 0 = the engine's choice for B) per (row, head)
+ * over all `len` cached positions, output already normalised and rounded: out = bf16 [B][H*64].  q fp32 [B][H*64]; row b's cache planes start at b * kv_row_stride elements
  * (bf16, each (H, max_seq, 64)).  Replaces [3p] flash_attn_func(q_len = 1) for a batch (meshanything.py:143-162 batch semantics). */
 MA_API int  ma_op_decode_attention_rows(const float *q, const void *kcache, const void *vcache, int H, int max_seq, int len, int B,
-                                        size_t kv_row_stride, void *out, void *stream);
+                                        size_t kv_row_stride, int waves, void *out, void *stream);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Time the decode step with HIP events on `stream` at KV length `kv_len` (cache contents arbitrary): `steps` back-to-back

@@ -293,17 +293,19 @@ inline hipError_t launch_attn_decode(const float* q, const void* kc, const void*
     return hipGetLastError();
 }
 
-// FINAL form for batches that fill the chip on (row, head) pairs alone (>= 16 rows x 16 heads = 256 blocks): one block per
-// (row, head), its 4 waves split ALL cached positions of the head (rounds of 128), the block-level merge finishes the softmax
-// and the normalised output goes straight to the out_proj GEMM's bf16 activation buffer -- no partials in HBM, no merge launch
-// ([3p] flash_attn_func with q_len 1, one call per layer).  Same per-slot arithmetic (attn_round_reduce) and block merge
-// (attn_fold_quarter / attn_fold_block) as the split form; only the grouping of positions into partial states differs.
-template <typename KT>
-__global__ __launch_bounds__(256) void attn_decode_final_kernel(const float* __restrict__ q, const KT* __restrict__ kc, const KT* __restrict__ vc,
-                                                                int max_seq, const DecState* st, int len_override, int round_q,
-                                                                bf16_t* __restrict__ out, int out_stride, int q_stride, size_t kv_row_stride) {
+// FINAL form for batches whose (row, head) pairs give the chip enough blocks: one block per (row, head), its NW waves split ALL
+// cached positions of the head (rounds of NW x 32), the block-level merge finishes the softmax and the normalised output goes
+// straight to the out_proj GEMM's bf16 activation buffer -- no partials in HBM, no merge launch ([3p] flash_attn_func with
+// q_len 1, one call per layer).  NW = 4 from 12 rows on (>= 192 blocks); 8 <= rows < 12 give 128-176 blocks, which stream
+// with NW = 8 waves each; below 8 rows the split form wins (too few blocks).  Same per-slot arithmetic
+// (attn_round_reduce) as the split form; only the grouping of positions into partial states differs.
+template <typename KT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float* __restrict__ q, const KT* __restrict__ kc, const KT* __restrict__ vc,
+                                                                    int max_seq, const DecState* st, int len_override, int round_q,
+                                                                    bf16_t* __restrict__ out, int out_stride, int q_stride, size_t kv_row_stride) {
     using G = AttnGeom<KT>;
     constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, U = G::U;
+    constexpr int RPOS = NW * 32;                           // positions per round of the block
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int h = blockIdx.x, brow = blockIdx.y;
     const int slot = lane / LPP, dsub = lane % LPP;
@@ -320,12 +322,12 @@ __global__ __launch_bounds__(256) void attn_decode_final_kernel(const float* __r
         }
     }
     const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
-    const int nround = (max(end, 0) + 127) >> 7;
+    const int nround = (max(end, 0) + RPOS - 1) / RPOS;
     const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
     const KT* vh = vc + (size_t)h * max_seq * 64 + dsub * EPL;
     u32x4 kA[U], vA[U], kB[U], vB[U];
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
-        const int base = (r << 7) + w * 32 + slot;
+        const int base = r * RPOS + w * 32 + slot;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = base + u * PPW;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_decode_final_kernel(const float* __r
     for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
     const u32x4 none = {0u, 0u, 0u, 0u};
     auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
-        attn_round_reduce<KT, false>(ss, qv, kr, vr, (r << 7) + w * 32 + slot, end, -1, none, none);
+        attn_round_reduce<KT, false>(ss, qv, kr, vr, r * RPOS + w * 32 + slot, end, -1, none, none);
     };
     if (round_q) {
 #pragma unroll
@@ -358,31 +360,55 @@ __global__ __launch_bounds__(256) void attn_decode_final_kernel(const float* __r
             reduce(r + 1, kB, vB);
         }
     }
-    __shared__ AttnMergeLds<KT> S;
+    // merge: wave w folds its own PPW slot states (lane = dim), then wave 0 folds the NW wave states (for NW = 4 this is
+    // attn_fold_quarter / attn_fold_block of the split form)
+    __shared__ float sm[NW * PPW], sl[NW * PPW], so[NW * PPW][64];
+    __shared__ float wm_[NW], wl_[NW], wo_[NW][64];
     const int gs = w * PPW + slot;
-    if (dsub == 0) { S.sm[gs] = ss.m; S.sl[gs] = ss.l; }
+    if (dsub == 0) { sm[gs] = ss.m; sl[gs] = ss.l; }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) S.so[gs][dsub * EPL + e] = ss.o[e];
+    for (int e = 0; e < EPL; ++e) so[gs][dsub * EPL + e] = ss.o[e];
     __syncthreads();
     {
-        float M, L, O;
-        attn_fold_quarter<KT>(S, w, lane, M, L, O);
-        if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
-        S.qo[w][lane] = O;
+        float M = -1e30f;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) M = fmaxf(M, sm[w * PPW + i]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const float f = expf(sm[w * PPW + i] - M);
+            L = fmaf(sl[w * PPW + i], f, L);
+            O = fmaf(so[w * PPW + i][lane], f, O);
+        }
+        if (lane == 0) { wm_[w] = M; wl_[w] = L; }
+        wo_[w][lane] = O;
     }
     __syncthreads();
     if (w == 0) {
-        float M, L, O;
-        attn_fold_block<KT>(S, lane, M, L, O);
+        float M = wm_[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) M = fmaxf(M, wm_[i]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const float f = expf(wm_[i] - M);
+            L = fmaf(wl_[i], f, L);
+            O = fmaf(wo_[i][lane], f, O);
+        }
         out[(size_t)brow * out_stride + h * 64 + lane] = f2bf(O * (1.0f / L));     // position 0 always exists: L > 0
     }
 }
 
 template <typename KT>
 inline hipError_t launch_attn_decode_final(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
-                                           int round_q, bf16_t* out, int out_stride, hipStream_t s, int batch, int q_stride, size_t kv_row_stride) {
-    hipLaunchKernelGGL((attn_decode_final_kernel<KT>), dim3(H, batch), dim3(256), 0, s, q, reinterpret_cast<const KT*>(kc),
-                       reinterpret_cast<const KT*>(vc), max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+                                           int round_q, bf16_t* out, int out_stride, hipStream_t s, int batch, int q_stride, size_t kv_row_stride,
+                                           int waves = 0) {
+    if (waves == 0) waves = batch >= 12 ? 4 : 8;          // measured: profiles/r02_ab_batched_attention_forms.txt
+    const KT* k = reinterpret_cast<const KT*>(kc); const KT* v = reinterpret_cast<const KT*>(vc);
+    if (waves == 4) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 4>), dim3(H, batch), dim3(256), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+    else if (waves == 8) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 8>), dim3(H, batch), dim3(512), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+    else if (waves == 16) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 16>), dim3(H, batch), dim3(1024), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

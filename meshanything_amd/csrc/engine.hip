@@ -104,7 +104,8 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
-    int opt_attn_final_min_batch = 16;   // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
+    int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
+    int opt_attn_final_waves = 0;        // waves per block of that form: 0 = 4 from 12 rows on, 8 below; or 4 | 8 | 16
     int opt_gemm_xcd_swizzle = 1;    // dense GEMM: hand the tiles out XCD-aware (gemm_tile.hpp)
     int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
@@ -387,7 +388,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         if (B >= e->opt_attn_final_min_batch) {
             // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
             if (tm.on(1)) {
-                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems);
+                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems, e->opt_attn_final_waves);
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode_final launch failed: ") + hipGetErrorString(r));
             }
         } else {
@@ -1025,6 +1026,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
+        else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
         else if (n == "gemv_small_rows") {
@@ -1061,6 +1063,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
+        else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "gemm_variant") *value = gemm_tile_variant();
         else throw MaError(MA_ERR_INVALID, "unknown option " + n);
@@ -1393,12 +1396,12 @@ int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, cons
 // batched single-query attention, final form (attn_decode_final_kernel): B rows, each its own cache plane, all of length `len`;
 // out = bf16 [B][H * 64]
 int ma_op_decode_attention_rows(const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int B, size_t kv_row_stride,
-                                void* out, void* stream) {
+                                int waves, void* out, void* stream) {
     return guarded(nullptr, [&] {
         if (!q || !kcache || !vcache || !out || H < 1 || B < 1 || len < 1 || len > max_seq || kv_row_stride < (size_t)H * max_seq * 64)
             throw MaError(MA_ERR_INVALID, "ma_op_decode_attention_rows: bad arguments");
         HIP_CHECK(launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64,
-                                                   reinterpret_cast<hipStream_t>(stream), B, H * 64, kv_row_stride));
+                                                   reinterpret_cast<hipStream_t>(stream), B, H * 64, kv_row_stride, waves));
     });
 }
 

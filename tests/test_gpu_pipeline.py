@@ -221,12 +221,12 @@ def test_large_batches_all_mfma_tile_counts(B):
     env.engine.set_option("mfma_min_batch", 4)
     same = int((ref == toks).all(dim=1).sum())
     assert same >= int(0.75 * B), f"only {same}/{B} rows equal the GEMV path"
-    # >= 16 rows: the attention launch writes the finished output (one block per (row, head)); below, split-KV partials + a
+    # >= 8 rows: the attention launch writes the finished output (one block per (row, head)); below, split-KV partials + a
     # merge launch.  Same arithmetic per position, different grouping of the partial softmax states.
-    assert env.engine.get_option("attn_final_min_batch") == 16
+    assert env.engine.get_option("attn_final_min_batch") == 8
     env.engine.set_option("attn_final_min_batch", 1000)
     split, split_len = env.engine.generate(prefix.cuda(), suppress_eos=True)
-    env.engine.set_option("attn_final_min_batch", 16)
+    env.engine.set_option("attn_final_min_batch", 8)
     _check_greedy(env, prefix, split, split_len, suppress_eos=True)
     same = int((split == toks).all(dim=1).sum())
     assert same >= int(0.75 * B), f"only {same}/{B} rows equal between the final and the split attention forms"
@@ -443,6 +443,15 @@ def test_full_batched_generate_matches_oracle(full, golden_dir):
         assert torch.equal(one[0], rowpar[0])
         same = int((rowpar == toks).all(dim=1).sum())
         print(f"[bf16] MFMA batch path vs GEMV batch path: {same}/6 rows token-identical over {n} tokens")
+        # the final-form attention (default from 8 rows on; 8 waves per (row, head) block below 12 rows) at the 350M shape
+        full.engine.set_option("attn_final_min_batch", 4)
+        fin, fin_len = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+        full.engine.set_option("attn_final_min_batch", 8)
+        vf = _check_greedy(full, prefix, fin, fin_len, suppress_eos=True)
+        assert all(r["ambiguous"] <= max(2, n // 20) for r in vf)
+        same = int((fin == toks).all(dim=1).sum())
+        print(f"[bf16] final-form vs split attention on the MFMA path: {same}/6 rows token-identical over {n} tokens")
+        assert same >= 4
 
 
 def test_full_length_generation_properties(full, golden_dir):
