@@ -59,16 +59,19 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
     for (int i = 0; i < 2; ++i) wo[i] = ld_stream16(a.Wo + (size_t)orow * KC + (i * 64 + lane) * 8);
     const float e_bo = a.bo[orow], e_res = a.res[(size_t)brow * a.res_stride + orow];
     u32x4 w1[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) w1[j][i] = ld_stream16(a.W1 + (size_t)(16 * b + 4 * w + j) * KC + (i * 64 + lane) * 8);
     float e_b1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e_b1[j] = a.b1[16 * b + 4 * w + j];
     f32x4 gv[1], bv[1];
-    gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
-    bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
+    auto load_fc1 = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) w1[j][i] = ld_stream16(a.W1 + (size_t)(16 * b + 4 * w + j) * KC + (i * 64 + lane) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e_b1[j] = a.b1[16 * b + 4 * w + j];
+        gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
+        bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
+    };
+    load_fc1();              // in the first instructions: requesting the fc1 rows under the exchange instead is 2 % slower (profiles/r02_ab_load_placement.txt)
     asm volatile("" ::: "memory");
 
     // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------

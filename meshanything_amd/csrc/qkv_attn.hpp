@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     const int start = c * per, end = min(len, start + per);
     const int nround = (max(end - start, 0) + 127) >> 7;
 
-    // ---- (1) loads, in consumption order: input vector (+ LayerNorm parameters), weight rows, bias, round 0 of the cache rows -----
+    // ---- (1) loads, in consumption order: input vector (+ LayerNorm parameters), weight rows, bias ------------------------------------
     f32x4 xv[1], gv[1], bv[1];
     float x0 = 0.f;
     xv[0] = *reinterpret_cast<const f32x4*>(x + tid * 4);
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
         for (int u = 0; u < G::U; ++u) { const int p = base + u * G::PPW; vr[u] = ld_stream16(vh + (size_t)(p < end ? p : start) * 64); }
     };
-    if (nround > 0) issue(0, kA, vA);
-    asm volatile("" ::: "memory");                       // pin the cache-row loads HERE (hipcc would sink them below the exchange)
+    asm volatile("" ::: "memory");                       // pin the weight / bias loads HERE
 
     // ---- (2) prologue + dot products: gemv_kernel<bf16_t, 1, 2, *, PRO> for the rows of this block --------------------------------
     if constexpr (PRO == PRO_LN) ln_block_onepass<1>(xv, gv, bv, x0, tid, KC / 4, KC, a.ln_eps, red);
@@ -130,6 +129,11 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     // ---- (3) exchange inside the head: publish 3 values per wave, wave 0 sweeps what this block needs -----------------------------
     u64* gran = a.gran + (size_t)brow * 3 * Hd;
     if (lane < 3) ps_publish(gran, lane * Hd + row, epoch, __float_as_uint(lane == 0 ? out3[0] : lane == 1 ? out3[1] : out3[2]));
+    // cache rows are requested once this block's q/k/v rows are out: they ride under the exchange and do not compete with the input
+    // vector and the weight rows on the way to the publish (-2 % per step against requesting them in the first instructions; a
+    // second round in flight buys nothing: profiles/r02_ab_load_placement.txt)
+    if (nround > 0) issue(0, kA, vA);
+    asm volatile("" ::: "memory");                       // pin them HERE (hipcc would sink them below the sweep)
     if (w == 0) {
         const gu64* g64 = (const gu64*)gran;
         const int nparts = c == c_last ? 3 : 1;          // q for everyone; k, v for the block that holds the newest position
