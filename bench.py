@@ -240,6 +240,7 @@ def main():
         mfma_path = args.batch >= 4 and args.dtype == "bf16"
         fused_qkv = bool(eng.get_option("fuse_qkv_attn")) and not mfma_path
         fused_o1 = bool(eng.get_option("fuse_oproj_fc1")) and not mfma_path
+        fused_f2 = fused_o1 and bool(eng.get_option("fuse_fc2"))
         qkv_w = cfg.layers * 3 * cfg.hidden * cfg.hidden * esz
         # the launches of a decode step fall in two classes (ma_profile_decode times each class alone, HIP events on the launch
         # stream around `profile_steps` steps; elapsed / launches = average launch duration, boundary to the next launch included --
@@ -255,7 +256,7 @@ def main():
                              "bytes_per_launch": int(byts / max(1, per_step)), "GBps": round(byts / max(1, per_step) / (ms / max(1, n_l) * 1e-3) / 1e9, 1),
                              "us_per_step": round(ms / args.profile_steps * 1e3, 1)}
         kern = {"weights": ("gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream)" if mfma_path else
-                            ("oproj_fc1_kernel + gemv_kernel (fc2, embed, lm_head)" if fused_o1 else "gemv_kernel") + " -- the launches that stream weight matrices only"),
+                            (("oproj_fc1_kernel (out_proj + LN + fc1 + fc2) + gemv_kernel (embed, lm_head)" if fused_f2 else "oproj_fc1_kernel + gemv_kernel (fc2, embed, lm_head)") if fused_o1 else "gemv_kernel") + " -- the launches that stream weight matrices only"),
                 "cache": ("qkv_attn_kernel (q/k/v projection + split-KV attention: q/k/v weights + the KV cache)" if fused_qkv else "attn_decode_kernel (KV cache)")}
         dom = max(classes, key=lambda k: classes[k]["us_per_step"])          # the class the step spends most of its time in
         dc = classes[dom]

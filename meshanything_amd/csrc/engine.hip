@@ -106,6 +106,8 @@ struct ma_engine {
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
     int opt_attn_final_waves = 0;        // waves per block of that form: 0 = 4 from 12 rows on, 8 below; or 4 | 8 | 16
+    int opt_fuse_fc2 = 1;                // fc2 inside the out_proj + fc1 launch (second in-launch all-gather, 4096 values)
+    int opt_oproj_fc1_sweep_waves = 4;   // fused out_proj + fc1 launch: waves per block polling the y1 granules (each its own quarter)
     int opt_gemm_xcd_swizzle = 1;    // dense GEMM: hand the tiles out XCD-aware (gemm_tile.hpp)
     int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
@@ -113,6 +115,7 @@ struct ma_engine {
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
+    u64* d_ffn_gran = nullptr;       // [max_batch][ffn] granules (fc2 in the out_proj + fc1 launch)
     unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
     int opt_decode_impl = 0;         // 0: chain of launches; 1: one persistent launch per step (when eligible)
     int n_cus = 0;
@@ -473,13 +476,17 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
     }
     }
+    bool fc2_done = false;
     if (fuse_oproj_fc1(e)) {
         // y1 = h + Wo a + bo; h1 = LN1(y1); f = relu(W1 h1 + b1) in one launch: y1 is all-gathered inside it (oproj_fc1.hpp)
         OprojFc1Args a{};
         a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b;
         a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.attn_ws = part; a.heads = c.heads; a.res = resid; a.h1_out = h1; a.ffn_out = ffn;
         a.st = e->d_st + r0; a.layer = l; a.gran = e->d_y1_gran + r0 * H; a.err = e->d_chain_err;
-        a.res_stride = H; a.h1_stride = H; a.ffn_stride = c.ffn;
+        a.res_stride = H; a.h1_stride = H; a.ffn_stride = c.ffn; a.sweep_waves = e->opt_oproj_fc1_sweep_waves;
+        const bool with_fc2 = e->opt_fuse_fc2 != 0;
+        fc2_done = with_fc2;
+        if (with_fc2) { a.W2 = reinterpret_cast<const bf16_t*>(w.fc2_w); a.b2 = w.fc2_b; a.y2_out = y2; a.y2_stride = H; a.gran2 = e->d_ffn_gran + r0 * c.ffn; }
         a.trace = tm.trace_slot(3, H / 4);
         if (tm.on(0)) {
             hipError_t r = launch_oproj_fc1(a, H, c.ffn, B, s);
@@ -502,7 +509,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         if (tm.on(0)) gemv(e, a, s, B);
     }
     }
-    {   // y2 = h1 + W2 f + b2
+    if (!fc2_done) {   // y2 = h1 + W2 f + b2
         GemvArgs a = gemv_base(e, rw);
         a.W = w.fc2_w; a.bias = w.fc2_b; a.x = ffn; a.x_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H; a.N = H; a.K = c.ffn;
         a.trace = tm.trace_slot(5, gemv_blocks(e, a.N, a.K));
@@ -715,6 +722,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     // the fused q/k/v + attention launch tags its exchange with the cache position, which restarts here
     HIP_CHECK(hipMemsetAsync(e->d_qkv_gran, 0, (size_t)e->cfg.max_batch * 3 * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_y1_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_ffn_gran, 0, (size_t)e->cfg.max_batch * e->cfg.ffn * sizeof(u64), s));
 }
 
 ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
@@ -884,6 +892,8 @@ void build_engine(ma_engine* e) {
     e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(1);
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
+    e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
+    HIP_CHECK(hipMemset(e->d_ffn_gran, 0, MB * (size_t)c.ffn * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_chain_err, 0, sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
@@ -1026,6 +1036,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
+        else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
+        else if (n == "fuse_fc2") { e->opt_fuse_fc2 = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
@@ -1063,6 +1075,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
+        else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
+        else if (n == "fuse_fc2") *value = e->opt_fuse_fc2;
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "gemm_variant") *value = gemm_tile_variant();

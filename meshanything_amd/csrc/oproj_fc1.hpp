@@ -33,11 +33,17 @@ struct OprojFc1Args {
     unsigned* err;
     int res_stride, h1_stride, ffn_stride;               // per batch row
     unsigned long long* trace;
+    int sweep_waves;                                     // waves per block that poll the y1 granules: 1 | 2 | 4
+    // fc2 in the same launch (template FC2): relu(fc1) is all-gathered too (4096 granules, a quarter per wave), then row 4b + w of fc2
+    const bf16_t* W2; const float* b2; float* y2_out; int y2_stride; u64* gran2;
 };
 constexpr unsigned OF_ERR_GATHER = 32;
 
+template <int NSW, bool FC2>
 __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
-    constexpr int KC = 1024;
+    constexpr int KC = 1024, KF = 4096;
+    __shared__ __attribute__((aligned(16))) float ffl[FC2 ? KF : 4];      // relu(fc1), rounded to bf16 (fc2's input)
+    __shared__ float h1l[FC2 ? 4 : 1];                                    // LN1(y1)[4b + w]: fc2's residual
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ __attribute__((aligned(16))) float yraw[KC];
     __shared__ float red[8];
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
         gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
         bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
     };
-    load_fc1();              // in the first instructions: requesting the fc1 rows under the exchange instead is 2 % slower (profiles/r02_ab_load_placement.txt)
+    load_fc1();              // in the first instructions: requesting the fc1 rows under the exchange instead is 2 % slower (profiles/r02_ab_exchange_and_load_placement.txt)
     asm volatile("" ::: "memory");
 
     // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------
@@ -107,22 +113,35 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
     // ---- (3) all-gather of y1: one granule per wave out, all 1024 in --------------------------------------------------
     u64* gran = a.gran + (size_t)brow * KC;
     if (lane == 0) ps_publish(gran, orow, epoch, __float_as_uint(y1));
-    if (w == 0) {                                        // ONE wave per block sweeps (MI355X guide, polling-cost): 16 granules per lane and pass
-        const gu64* g64 = (const gu64*)gran;
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
-        unsigned spins = 0, pend = 0xffffu;
-        for (;;) {
-            u64 v[16];
+    u32x4 w2[FC2 ? 8 : 1];
+    float e_b2 = 0.f;
+    if constexpr (FC2) {                                 // fc2's row: not needed before the second exchange, requested under the first
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+        for (int i = 0; i < 8; ++i) w2[i] = ld_stream16(a.W2 + (size_t)orow * KF + (i * 64 + lane) * 8);
+        e_b2 = a.b2[orow];
+        asm volatile("" ::: "memory");
+    }
+    // NSW waves per block sweep, each its own 1024 / NSW granules (16 / NSW per lane and pass).  The polling traffic is what costs (MI355X
+    // guide): four waves that each polled ALL granules lost 1.2 %; four waves polling a quarter each win 4 % over one wave polling all
+    // (profiles/r02_ab_exchange_and_load_placement.txt)
+    if (w < NSW) {
+        constexpr int NK = 16 / NSW;
+        const gu64* g64 = (const gu64*)gran + w * NK * 64;
+        float* yr = yraw + w * NK * 64;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0, pend = (1u << NK) - 1u;
+        for (;;) {
+            u64 v[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
                 v[k] = (u64)epoch << 32;
                 if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < NK; ++k) {
                 if ((pend >> k) & 1u) {
                     const bool ok = (unsigned)(v[k] >> 32) == epoch;
-                    if (ok) yraw[k * 64 + lane] = __uint_as_float((unsigned)v[k]);
+                    if (ok) yr[k * 64 + lane] = __uint_as_float((unsigned)v[k]);
                     if (__all(ok)) pend &= ~(1u << k);
                 }
             }
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
             if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
                 if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) yraw[k * 64 + lane] = 0.f;
+                for (int k = 0; k < NK; ++k) yr[k * 64 + lane] = 0.f;
                 break;
             }
         }
@@ -145,7 +164,8 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
         xv[0] = *reinterpret_cast<const f32x4*>(&yraw[tid * 4]);
         const float x0 = yraw[0];
         ln_block_onepass<1>(xv, gv, bv, x0, tid, KC / 4, KC, a.ln_eps, red);
-        if (b == 0) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)brow * a.h1_stride + tid * 4) = xv[0];
+        if constexpr (FC2) { if (tid == b) { h1l[0] = xv[0].x; h1l[1] = xv[0].y; h1l[2] = xv[0].z; h1l[3] = xv[0].w; } }   // elements 4b .. 4b + 3
+        else if (b == 0) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)brow * a.h1_stride + tid * 4) = xv[0];
         f32x4 r = xv[0];
         r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
@@ -177,13 +197,73 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
         v = fmaxf(v, 0.0f);
         if (lane == j) outv = v;
     }
-    if (lane < 4) a.ffn_out[(size_t)brow * a.ffn_stride + 16 * b + 4 * w + lane] = outv;
-    if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (!FC2) {
+        if (lane < 4) a.ffn_out[(size_t)brow * a.ffn_stride + 16 * b + 4 * w + lane] = outv;
+        if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    } else {
+        // ---- (5) all-gather of relu(fc1): 4 granules per wave out, wave w sweeps granules [1024 w, 1024 w + 1024) -----------------------
+        u64* g2 = a.gran2 + (size_t)brow * KF;
+        if (lane < 4) ps_publish(g2, 16 * b + 4 * w + lane, epoch, __float_as_uint(outv));
+        {
+            const gu64* g64 = (const gu64*)g2 + w * 1024;
+            float* fr = ffl + w * 1024;
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0, pend = 0xffffu;
+            for (;;) {
+                u64 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    v[k] = (u64)epoch << 32;
+                    if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if ((pend >> k) & 1u) {
+                        const bool ok = (unsigned)(v[k] >> 32) == epoch;
+                        if (ok) fr[k * 64 + lane] = round_bf16(__uint_as_float((unsigned)v[k]));
+                        if (__all(ok)) pend &= ~(1u << k);
+                    }
+                }
+                if (!pend) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                    if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) fr[k * 64 + lane] = 0.f;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        // ---- (6) fc2: gemv_kernel<bf16_t, 1, 8, 1, PRO_PLAIN>, row 4b + w ---------------------------------------------------------------
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k0 = (i * 64 + lane) * 8;
+            float xs[8], wf[8];
+#pragma unroll
+            for (int v = 0; v < 8; v += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&ffl[k0 + v]);
+                xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
+            }
+            unpack16<bf16_t>(w2[i], wf);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
+        }
+        float v = wave_sum(acc);
+        v += e_b2;
+        v += h1l[w];
+        if (lane == 0) a.y2_out[(size_t)brow * a.y2_stride + orow] = v;
+    }
 }
 
 inline hipError_t launch_oproj_fc1(const OprojFc1Args& a, int hidden, int ffn, int batch, hipStream_t s) {
     if (hidden != 1024 || ffn != 4096 || a.heads * 64 != hidden) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(oproj_fc1_kernel, dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    if (a.W2) hipLaunchKernelGGL((oproj_fc1_kernel<4, true>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else if (a.sweep_waves == 2) hipLaunchKernelGGL((oproj_fc1_kernel<2, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else if (a.sweep_waves == 4) hipLaunchKernelGGL((oproj_fc1_kernel<4, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((oproj_fc1_kernel<1, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     if (lane < 3) ps_publish(gran, lane * Hd + row, epoch, __float_as_uint(lane == 0 ? out3[0] : lane == 1 ? out3[1] : out3[2]));
     // cache rows are requested once this block's q/k/v rows are out: they ride under the exchange and do not compete with the input
     // vector and the weight rows on the way to the publish (-2 % per step against requesting them in the first instructions; a
-    // second round in flight buys nothing: profiles/r02_ab_load_placement.txt)
+    // second round in flight buys nothing: profiles/r02_ab_exchange_and_load_placement.txt)
     if (nround > 0) issue(0, kA, vA);
     asm volatile("" ::: "memory");                       // pin them HERE (hipcc would sink them below the sweep)
     if (w == 0) {
