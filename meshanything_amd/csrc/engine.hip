@@ -31,6 +31,7 @@
 #include "oproj_fc1.hpp"
 #include "persist.hpp"
 #include "qkv_attn.hpp"
+#include "layer_fused.hpp"
 #include "state.hpp"
 #include "weights.hpp"
 
@@ -106,6 +107,7 @@ struct ma_engine {
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
     int opt_attn_final_waves = 0;        // waves per block of that form: 0 = 4 from 12 rows on, 8 below; or 4 | 8 | 16
+    int opt_fuse_layer = 0;              // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp)
     int opt_fuse_fc2 = 1;                // fc2 inside the out_proj + fc1 launch (second in-launch all-gather, 4096 values)
     int opt_oproj_fc1_sweep_waves = 4;   // fused out_proj + fc1 launch: waves per block polling the y1 granules (each its own quarter)
     int opt_gemm_xcd_swizzle = 1;    // dense GEMM: hand the tiles out XCD-aware (gemm_tile.hpp)
@@ -115,6 +117,7 @@ struct ma_engine {
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
+    u64* d_y2_gran = nullptr;        // [max_batch][hidden] granules (y2 handed to the next layer inside a launch)
     u64* d_ffn_gran = nullptr;       // [max_batch][ffn] granules (fc2 in the out_proj + fc1 launch)
     unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
     int opt_decode_impl = 0;         // 0: chain of launches; 1: one persistent launch per step (when eligible)
@@ -439,7 +442,33 @@ bool fuse_oproj_fc1(ma_engine* e) { return e->opt_fuse_oproj_fc1 && e->bf16 && e
 bool fuse_qkv_attn(ma_engine* e) { return e->opt_fuse_qkv_attn && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
 
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
-void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw) {
+QkvAttnArgs make_qkv_attn_args(ma_engine* e, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, Rows rw) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden; const size_t r0 = rw.r0;
+    const DecLayerPtrs& w = e->dl[l];
+    QkvAttnArgs a{};
+    a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? e->d_h0 + r0 * H : nullptr;
+    a.kcache = reinterpret_cast<bf16_t*>(e->kplane(rw.r0, l)); a.vcache = reinterpret_cast<bf16_t*>(e->vplane(rw.r0, l)); a.max_seq = e->maxseq; a.hidden = H;
+    a.st = e->d_st + r0; a.len_override = len_override; a.layer = l; a.ws = e->d_part + r0 * attn_workspace_floats(c.heads); a.gran = e->d_qkv_gran + r0 * 3 * H; a.err = e->d_chain_err;
+    a.x_stride = H; a.xn_stride = H; a.kv_row_stride = e->kv_row_bytes / e->kv_elem;
+    return a;
+}
+OprojFc1Args make_oproj_fc1_args(ma_engine* e, int l, const float* resid, Rows rw, bool with_fc2) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden; const size_t r0 = rw.r0;
+    const DecLayerPtrs& w = e->dl[l];
+    OprojFc1Args a{};
+    a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b;
+    a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.attn_ws = e->d_part + r0 * attn_workspace_floats(c.heads); a.heads = c.heads; a.res = resid;
+    a.h1_out = e->d_h1 + r0 * H; a.ffn_out = e->d_ffn + r0 * c.ffn;
+    a.st = e->d_st + r0; a.layer = l; a.gran = e->d_y1_gran + r0 * H; a.err = e->d_chain_err;
+    a.res_stride = H; a.h1_stride = H; a.ffn_stride = c.ffn; a.sweep_waves = e->opt_oproj_fc1_sweep_waves;
+    if (with_fc2) { a.W2 = reinterpret_cast<const bf16_t*>(w.fc2_w); a.b2 = w.fc2_b; a.y2_out = e->d_ypre2 + r0 * H; a.y2_stride = H; a.gran2 = e->d_ffn_gran + r0 * c.ffn; }
+    return a;
+}
+
+// parts: 1 = the layer's first half (LayerNorm + q/k/v + attention), 2 = its second half (out_proj .. fc2), 3 = both
+void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, StepTimer& tm, Rows rw, int parts = 3) {
     const ma_config& c = e->cfg;
     const int H = c.hidden, B = rw.B;
     const size_t r0 = rw.r0;
@@ -448,13 +477,10 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     float* h1 = e->d_h1 + r0 * H; float* ffn = e->d_ffn + r0 * c.ffn; float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
     const float* resid = ln_g ? h0 : x_in;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
-    if (fuse_qkv_attn(e)) {
+    if (!(parts & 1)) {
+    } else if (fuse_qkv_attn(e)) {
         // q, k, v projection + split-KV attention in one launch (qkv_attn.hpp): the exchange between them stays inside a head
-        QkvAttnArgs a{};
-        a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.x = x_in; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; a.xn_out = ln_g ? h0 : nullptr;
-        a.kcache = reinterpret_cast<bf16_t*>(e->kplane(rw.r0, l)); a.vcache = reinterpret_cast<bf16_t*>(e->vplane(rw.r0, l)); a.max_seq = e->maxseq; a.hidden = H;
-        a.st = e->d_st + r0; a.len_override = len_override; a.layer = l; a.ws = part; a.gran = e->d_qkv_gran + r0 * 3 * H; a.err = e->d_chain_err;
-        a.x_stride = H; a.xn_stride = H; a.kv_row_stride = kv_row_elems;
+        QkvAttnArgs a = make_qkv_attn_args(e, l, x_in, ln_g, ln_b, len_override, rw);
         a.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
         if (tm.on(1)) {
             hipError_t r = launch_qkv_attn(a, c.heads, B, s);
@@ -477,16 +503,12 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     }
     }
     bool fc2_done = false;
+    if (!(parts & 2)) return;
     if (fuse_oproj_fc1(e)) {
-        // y1 = h + Wo a + bo; h1 = LN1(y1); f = relu(W1 h1 + b1) in one launch: y1 is all-gathered inside it (oproj_fc1.hpp)
-        OprojFc1Args a{};
-        a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b;
-        a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.attn_ws = part; a.heads = c.heads; a.res = resid; a.h1_out = h1; a.ffn_out = ffn;
-        a.st = e->d_st + r0; a.layer = l; a.gran = e->d_y1_gran + r0 * H; a.err = e->d_chain_err;
-        a.res_stride = H; a.h1_stride = H; a.ffn_stride = c.ffn; a.sweep_waves = e->opt_oproj_fc1_sweep_waves;
+        // y1 = h + Wo a + bo; h1 = LN1(y1); f = relu(W1 h1 + b1) [; y2 = h1 + W2 f + b2] in one launch: y1 (and f) all-gathered inside it (oproj_fc1.hpp)
         const bool with_fc2 = e->opt_fuse_fc2 != 0;
         fc2_done = with_fc2;
-        if (with_fc2) { a.W2 = reinterpret_cast<const bf16_t*>(w.fc2_w); a.b2 = w.fc2_b; a.y2_out = y2; a.y2_stride = H; a.gran2 = e->d_ffn_gran + r0 * c.ffn; }
+        OprojFc1Args a = make_oproj_fc1_args(e, l, resid, rw, with_fc2);
         a.trace = tm.trace_slot(3, H / 4);
         if (tm.on(0)) {
             hipError_t r = launch_oproj_fc1(a, H, c.ffn, B, s);
@@ -514,6 +536,21 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         a.W = w.fc2_w; a.bias = w.fc2_b; a.x = ffn; a.x_stride = c.ffn; a.res = h1; a.res_stride = H; a.y = y2; a.y_stride = H; a.N = H; a.K = c.ffn;
         a.trace = tm.trace_slot(5, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, B);
+    }
+}
+
+bool fuse_layer(ma_engine* e) { return e->opt_fuse_layer && fuse_qkv_attn(e) && fuse_oproj_fc1(e) && e->opt_fuse_fc2; }
+
+// second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp); belongs to the "cache" class of the profiler
+void enqueue_layer_pair(ma_engine* e, hipStream_t s, int l, const float* resid, int len_override, StepTimer& tm, Rows rw) {
+    const ma_config& c = e->cfg;
+    LayerFusedArgs a{};
+    a.o = make_oproj_fc1_args(e, l, resid, rw, true);
+    a.q = make_qkv_attn_args(e, l + 1, nullptr, e->dl[l].ln2_g, e->dl[l].ln2_b, len_override, rw);
+    a.gran3 = e->d_y2_gran + (size_t)rw.r0 * c.hidden;
+    if (tm.on(1)) {
+        hipError_t r = launch_layer_fused(a, c.hidden, c.ffn, c.heads, rw.B, s);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("layer_fused launch failed: ") + hipGetErrorString(r));
     }
 }
 
@@ -616,6 +653,13 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         enqueue_layers_mfma(e, s, de, len_override, tm, rw);
     } else {
         const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
+        if (fuse_layer(e) && c.layers >= 2) {
+            // first half of layer 0 | (second half of l + first half of l + 1) x (L - 1) | second half of layer L - 1
+            const float* h0 = e->d_h0 + (size_t)rw.r0 * H;
+            enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw, 1);
+            for (int l = 0; l + 1 < c.layers; ++l) enqueue_layer_pair(e, s, l, l == 0 ? de : h0, len_override, tm, rw);
+            enqueue_layer(e, s, c.layers - 1, y2, e->dl[c.layers - 2].ln2_g, e->dl[c.layers - 2].ln2_b, len_override, tm, rw, 2);
+        } else
         for (int l = 0; l < c.layers; ++l) {
             if (l == 0) enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw);
             else enqueue_layer(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, len_override, tm, rw);
@@ -723,6 +767,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipMemsetAsync(e->d_qkv_gran, 0, (size_t)e->cfg.max_batch * 3 * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_y1_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_ffn_gran, 0, (size_t)e->cfg.max_batch * e->cfg.ffn * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_y2_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
 }
 
 ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
@@ -892,6 +937,8 @@ void build_engine(ma_engine* e) {
     e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(1);
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
+    e->d_y2_gran = e->dmalloc<u64>(MB * H);
+    HIP_CHECK(hipMemset(e->d_y2_gran, 0, MB * H * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
     HIP_CHECK(hipMemset(e->d_ffn_gran, 0, MB * (size_t)c.ffn * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
@@ -1038,6 +1085,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
         else if (n == "fuse_fc2") { e->opt_fuse_fc2 = (int)value; drop_graphs(e); }
+        else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
@@ -1077,6 +1125,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
         else if (n == "fuse_fc2") *value = e->opt_fuse_fc2;
+        else if (n == "fuse_layer") *value = fuse_layer(e) ? 1 : 0;
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "gemm_variant") *value = gemm_tile_variant();

@@ -39,8 +39,11 @@ struct OprojFc1Args {
 };
 constexpr unsigned OF_ERR_GATHER = 32;
 
-template <int NSW, bool FC2>
-__global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
+// NEXT: instead of storing y2, all-gather it (1024 granules in `gran3`, a quarter per wave) into `ynext` (LDS, 1024 floats): the next
+// layer's q/k/v + attention continues in the same launch (layer_fused.hpp).  Arguments by value: a by-reference kernel-argument
+// struct can end up in scratch.
+template <int NSW, bool FC2, bool NEXT, typename Hook>
+__device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, const int brow, float* ynext, u64* gran3, Hook&& after_ffn_publish) {
     constexpr int KC = 1024, KF = 4096;
     __shared__ __attribute__((aligned(16))) float ffl[FC2 ? KF : 4];      // relu(fc1), rounded to bf16 (fc2's input)
     __shared__ float h1l[FC2 ? 4 : 1];                                    // LN1(y1)[4b + w]: fc2's residual
@@ -48,7 +51,6 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
     __shared__ __attribute__((aligned(16))) float yraw[KC];
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.x, brow = blockIdx.y;
     if (a.trace && tid == 0) a.trace[b * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const float* ws = a.attn_ws + (size_t)brow * attn_workspace_floats(a.heads);
     const unsigned epoch = (unsigned)a.st[brow].pos * 32u + (unsigned)a.layer + 1u;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
         // ---- (5) all-gather of relu(fc1): 4 granules per wave out, wave w sweeps granules [1024 w, 1024 w + 1024) -----------------------
         u64* g2 = a.gran2 + (size_t)brow * KF;
         if (lane < 4) ps_publish(g2, 16 * b + 4 * w + lane, epoch, __float_as_uint(outv));
+        after_ffn_publish();                             // the caller's next requests ride under this exchange
         {
             const gu64* g64 = (const gu64*)g2 + w * 1024;
             float* fr = ffl + w * 1024;
@@ -254,8 +257,48 @@ __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
         float v = wave_sum(acc);
         v += e_b2;
         v += h1l[w];
-        if (lane == 0) a.y2_out[(size_t)brow * a.y2_stride + orow] = v;
+        if constexpr (!NEXT) {
+            if (lane == 0) a.y2_out[(size_t)brow * a.y2_stride + orow] = v;
+        } else {
+            // ---- (7) all-gather of y2 for the next layer's LayerNorm: one granule per wave out, a quarter of the 1024 per wave in ----------
+            u64* g3 = gran3 + (size_t)brow * KC;
+            if (lane == 0) ps_publish(g3, orow, epoch, __float_as_uint(v));
+            const gu64* g64 = (const gu64*)g3 + w * 256;
+            float* yr = ynext + w * 256;
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0, pend = 0xfu;
+            for (;;) {
+                u64 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    q[k] = (u64)epoch << 32;
+                    if ((pend >> k) & 1u) q[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((pend >> k) & 1u) {
+                        const bool ok = (unsigned)(q[k] >> 32) == epoch;
+                        if (ok) yr[k * 64 + lane] = __uint_as_float((unsigned)q[k]);
+                        if (__all(ok)) pend &= ~(1u << k);
+                    }
+                }
+                if (!pend) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                    if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yr[k * 64 + lane] = 0.f;
+                    break;
+                }
+            }
+            __syncthreads();
+        }
     }
+}
+
+template <int NSW, bool FC2>
+__global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
+    oproj_fc1_body<NSW, FC2, false>(a, blockIdx.x, blockIdx.y, nullptr, nullptr, [] {});
 }
 
 inline hipError_t launch_oproj_fc1(const OprojFc1Args& a, int hidden, int ffn, int batch, hipStream_t s) {

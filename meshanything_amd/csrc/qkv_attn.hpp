@@ -39,8 +39,31 @@ struct QkvAttnArgs {
 };
 constexpr unsigned QA_ERR_GATHER = 16;
 
+// the operands of a block that do not depend on the input vector: its 12 weight rows (4 waves x q, k, v), their biases, the LayerNorm
+// parameters.  A caller that runs other work first (layer_fused.hpp) requests them early and hands them over.
+struct QkvOperands { u32x4 wv[3][2]; float bq[3]; f32x4 gv, bv; };
 template <int PRO>
-__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
+__device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const int c, const int h, QkvOperands& op) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if constexpr (PRO == PRO_LN) {
+        op.gv = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
+        op.bv = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
+    }
+    const int row = 64 * h + 4 * c + w;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const bf16_t* wr = a.W + (size_t)(p * a.hidden + row) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) op.wv[p][i] = ld_stream16(wr + (i * 64 + lane) * 8);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) op.bq[p] = a.bias[p * a.hidden + row];
+}
+
+// XLDS: the input vector is already in LDS (`xlds`, 1024 floats; layer_fused.hpp) instead of global memory, and the operands were
+// requested by the caller.
+template <int PRO, bool XLDS>
+__device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const int h, const int nheads, const int brow, const float* xlds, QkvOperands& op) {
     typedef AttnGeom<bf16_t> G;
     constexpr int KC = 1024;
     __shared__ __attribute__((aligned(16))) float xl[KC];
@@ -49,9 +72,8 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t kvg[128];        // newest position's k_h | v_h as bf16 (what the cache holds)
     __shared__ AttnMergeLds<bf16_t> S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c = blockIdx.x, h = blockIdx.y, nheads = gridDim.y, brow = blockIdx.z;
     const int Hd = a.hidden;
-    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const float* x = a.x + (size_t)brow * a.x_stride;
     const DecState sv = a.st[brow];
     const int len = a.len_override >= 0 ? a.len_override : sv.pos + 1;
@@ -62,25 +84,14 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     const int nround = (max(end - start, 0) + 127) >> 7;
 
     // ---- (1) loads, in consumption order: input vector (+ LayerNorm parameters), weight rows, bias ------------------------------------
-    f32x4 xv[1], gv[1], bv[1];
+    f32x4 xv[1];
     float x0 = 0.f;
-    xv[0] = *reinterpret_cast<const f32x4*>(x + tid * 4);
-    if constexpr (PRO == PRO_LN) {
-        x0 = x[0];
-        gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
-        bv[0] = *reinterpret_cast<const f32x4*>(a.ln_b + tid * 4);
-    }
+    if constexpr (XLDS) xv[0] = *reinterpret_cast<const f32x4*>(xlds + tid * 4);
+    else xv[0] = *reinterpret_cast<const f32x4*>(x + tid * 4);
+    if constexpr (PRO == PRO_LN) x0 = XLDS ? xlds[0] : x[0];
+    if constexpr (!XLDS) qkv_load_operands<PRO>(a, c, h, op);
     const int row = 64 * h + 4 * c + w;                  // this wave's row inside each of the q, k, v blocks of the fused matrix
-    u32x4 wv[3][2];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const bf16_t* wr = a.W + (size_t)(p * Hd + row) * KC;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wv[p][i] = ld_stream16(wr + (i * 64 + lane) * 8);
-    }
-    float bq[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) bq[p] = a.bias[p * Hd + row];
+    f32x4 gv[1] = {op.gv}, bv[1] = {op.bv};
     const int slot = lane / G::LPP, dsub = lane % G::LPP, woff = w * 32;
     const bf16_t* kh = a.kcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
     const bf16_t* vh = a.vcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
@@ -116,15 +127,15 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             float wf[8];
-            unpack16<bf16_t>(wv[p][i], wf);
+            unpack16<bf16_t>(op.wv[p][i], wf);
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc[p] = fmaf(wf[v], xs[v], acc[p]);
         }
     }
     float out3[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) { float v = wave_sum(acc[p]); v += bq[p]; out3[p] = v; }
-    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    for (int p = 0; p < 3; ++p) { float v = wave_sum(acc[p]); v += op.bq[p]; out3[p] = v; }
+    if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- (3) exchange inside the head: publish 3 values per wave, wave 0 sweeps what this block needs -----------------------------
     u64* gran = a.gran + (size_t)brow * 3 * Hd;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
         }
     }
     __syncthreads();
-    if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- (4) attention over chunk c (attn_decode.hpp, the launch chain's arithmetic; the newest position from the granules) ----------
     float qv[G::EPL];
@@ -210,8 +221,14 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
         float* op = ws + (size_t)nheads * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
         if (lane == 0) { ml[0] = M; ml[1] = L; }
         op[lane] = O;
-        if (a.trace && tid == 0) a.trace[(blockIdx.y * ATTN_NCHUNK + blockIdx.x) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
+    QkvOperands op;
+    qkv_attn_body<PRO, false>(a, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, nullptr, op);
 }
 
 inline hipError_t launch_qkv_attn(const QkvAttnArgs& a, int heads, int batch, hipStream_t s) {

@@ -206,3 +206,37 @@ def test_fc2_inside_the_oproj_fc1_launch_is_bitwise(eng):
             row[fuse] = eng.profile_decode(L, 16)["step_ms_graph"] * 1e3
         eng.set_option("fuse_fc2", default)
         print(f"[fc2 inside oproj+fc1 A/B] kv_len {L:5d}: separate fc2 launch {row[0]:7.1f} us/step | fused {row[1]:7.1f} us/step | ratio {row[1] / row[0]:.3f}")
+
+
+@pytest.mark.gpu
+def test_layer_pair_launch_is_bitwise(eng):
+    """fuse_layer: the second half of layer l and the first half of layer l + 1 in one launch (csrc/layer_fused.hpp; y2 all-gathered
+    inside it).  Same device functions as the two launches it replaces: bit-identical logits and tokens, batch 1 and 2 rows."""
+    default = eng.get_option("fuse_layer")
+    def run(fuse, prefix, n):
+        eng.set_option("fuse_layer", fuse)
+        try:
+            assert eng.get_option("fuse_layer") == fuse
+            toks, _ = eng.generate(prefix, max_new_tokens=n, suppress_eos=True)
+            lg = [eng.read_logits(r).clone() for r in range(prefix.shape[0])]
+        finally:
+            eng.set_option("fuse_layer", default)
+        torch.cuda.synchronize()
+        return toks.cpu(), [x.cpu() for x in lg]
+    for n in (2, 9, 130):
+        t0, g0 = run(0, eng.prefix, n)
+        t1, g1 = run(1, eng.prefix, n)
+        assert torch.equal(t0, t1), (n, t0.tolist(), t1.tolist())
+        assert torch.equal(g0[0].view(torch.int32), g1[0].view(torch.int32)), f"layer pair: logits differ after {n} tokens: {float((g0[0] - g1[0]).abs().max()):.3e}"
+    two = torch.cat([eng.prefix, eng.prefix.flip(1)])
+    t0, g0 = run(0, two, 40)
+    t1, g1 = run(1, two, 40)
+    assert torch.equal(t0, t1) and all(torch.equal(g0[r].view(torch.int32), g1[r].view(torch.int32)) for r in range(2))
+    for L in (300, 3858, eng.cfg.max_seq - 80):
+        row = {}
+        for fuse in (0, 1, 0, 1):
+            eng.set_option("fuse_layer", fuse)
+            eng.profile_decode(L, 2)
+            row[fuse] = eng.profile_decode(L, 16)["step_ms_graph"] * 1e3
+        eng.set_option("fuse_layer", default)
+        print(f"[layer pair A/B] kv_len {L:5d}: two launches per layer {row[0]:7.1f} us/step | one {row[1]:7.1f} us/step | ratio {row[1] / row[0]:.3f}")
