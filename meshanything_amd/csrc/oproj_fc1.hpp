@@ -203,27 +203,31 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         if (lane < 4) a.ffn_out[(size_t)brow * a.ffn_stride + 16 * b + 4 * w + lane] = outv;
         if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     } else {
-        // ---- (5) all-gather of relu(fc1): 4 granules per wave out, wave w sweeps granules [1024 w, 1024 w + 1024) -----------------------
+        // ---- (5) all-gather of relu(fc1).  fc2 consumes it rounded to bf16, so a granule carries TWO values (bf16 pair + epoch): 2 granules
+        //      per wave out, 2048 in all, wave w sweeps granules [512 w, 512 w + 512) -- half the polling of one value per granule ------------
         u64* g2 = a.gran2 + (size_t)brow * KF;
-        if (lane < 4) ps_publish(g2, 16 * b + 4 * w + lane, epoch, __float_as_uint(outv));
+        {
+            const float nb = __shfl_down(outv, 1, 64);
+            if (lane == 0 || lane == 2) ps_publish(g2, 8 * b + 2 * w + (lane >> 1), epoch, (unsigned)f2bf(outv) | ((unsigned)f2bf(nb) << 16));
+        }
         after_ffn_publish();                             // the caller's next requests ride under this exchange
         {
-            const gu64* g64 = (const gu64*)g2 + w * 1024;
+            const gu64* g64 = (const gu64*)g2 + w * 512;
             float* fr = ffl + w * 1024;
             const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned spins = 0, pend = 0xffffu;
+            unsigned spins = 0, pend = 0xffu;
             for (;;) {
-                u64 v[16];
+                u64 v[8];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     v[k] = (u64)epoch << 32;
                     if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < 8; ++k) {
                     if ((pend >> k) & 1u) {
                         const bool ok = (unsigned)(v[k] >> 32) == epoch;
-                        if (ok) fr[k * 64 + lane] = round_bf16(__uint_as_float((unsigned)v[k]));
+                        if (ok) { const unsigned pr = (unsigned)v[k]; fr[2 * (k * 64 + lane)] = bf_lo(pr); fr[2 * (k * 64 + lane) + 1] = bf_hi(pr); }
                         if (__all(ok)) pend &= ~(1u << k);
                     }
                 }
@@ -232,7 +236,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
                     if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) fr[k * 64 + lane] = 0.f;
+                    for (int k = 0; k < 8; ++k) { fr[2 * (k * 64 + lane)] = 0.f; fr[2 * (k * 64 + lane) + 1] = 0.f; }
                     break;
                 }
             }
