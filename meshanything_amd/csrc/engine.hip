@@ -391,7 +391,9 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
             gemm_dec(e, s, a, tm);
         }
-        if (B >= e->opt_attn_final_min_batch) {
+        // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
+        // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
+        if (B >= e->opt_attn_final_min_batch && (B >= 12 || e->maxseq <= 8192)) {
             // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
             if (tm.on(1)) {
                 hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems, e->opt_attn_final_waves);
