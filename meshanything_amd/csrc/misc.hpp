@@ -70,13 +70,16 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     __shared__ float cv[PICK_KMAX]; __shared__ int ci[PICK_KMAX];
     __shared__ int chosen;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int do_sample = st->do_sample;
+    // the state record and the argmax partials are requested together (the partials do not depend on the state: a sampled step
+    // just drops them) -- one memory round trip instead of two in front of the greedy reduction
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+    const DecState sv = *st;
+    const int do_sample = sv.do_sample;
     if (!do_sample) {
-        float bv = -INFINITY; int bi = 0x7fffffff;
-        if (nparts > 0) {            // per-block partials of the lm_head GEMV (eos already excluded there when suppressed)
-            for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+        if (nparts > 0) {            // per-block partials of the lm_head GEMV (eos already excluded there when suppressed): reduced above
         } else {                     // batched MFMA lm_head: plain logits
-            const int skip = st->suppress_eos ? TOK_EOS : -1;
+            const int skip = sv.suppress_eos ? TOK_EOS : -1;
             for (int i = tid; i < V; i += 256) { const float v = logits[i]; if (i != skip && arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
         }
 #pragma unroll
@@ -177,10 +180,10 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     }
     __syncthreads();
     if (tid == 0) {
-        const int t = st->t;
+        const int t = sv.t;
         int tok = chosen;
-        if (st->finished) tok = TOK_PAD;
-        if (t < st->max_new) tokens_out[t] = tok;
+        if (sv.finished) tok = TOK_PAD;
+        if (t < sv.max_new) tokens_out[t] = tok;
         if (tok == TOK_EOS) st->finished = 1;
         st->cur_tok = tok;
         st->t = t + 1;
