@@ -126,6 +126,8 @@ def test_persistent_step_timing_report(eng):
 def test_fused_qkv_attention_launch_is_bitwise_the_two_launches(eng):
     """The launch chain's fused q/k/v + attention launch (csrc/qkv_attn.hpp, default) against the two launches it replaces
     (fuse_qkv_attn = 0): same arithmetic, so bit-identical logits and identical tokens -- batch 1 and a batch of 2 rows."""
+    # on a whole MI355X the fused launches are what runs (their 256 blocks are resident together with margin)
+    assert eng.get_option("chain_resident") == 1 and eng.get_option("fuse_qkv_attn") == 1 and eng.get_option("fuse_oproj_fc1") == 1 and eng.get_option("fuse_fc2") == 1
     def run(fuse, prefix, n, opt="fuse_qkv_attn"):
         eng.set_option(opt, fuse)
         try:
