@@ -233,6 +233,12 @@ MA_API int  ma_profile_decode(ma_engine *e, int kv_len, int steps, ma_kernel_tim
 MA_API int  ma_trace_decode(ma_engine *e, int kv_len, uint64_t *host_out, int max_launches, int max_blocks, int32_t *kinds,
                             int32_t *blocks, int32_t *n_launches, void *stream);
 
+/* ma_op_gemm_dec_ln (B <= 16, K = 1024): the same GEMM with the LayerNorm prologue of ma_op_rows_prologue inside it -- activation row b =
+ * LN(sum of `parts` partial buffers pin[parts][B][1024] + pbias + pres[b]) rounded to bf16; xn_out (B, 1024) fp32 = the LayerNorm
+ * output (may be NULL).  The batched decode path's form for small batches ([3p] OPTDecoderLayer post-LN + Linear). */
+MA_API int  ma_op_gemm_dec_ln(const void *W, const float *bias, const float *pin, int parts, const float *pbias, const float *pres,
+                              const float *ln_g, const float *ln_b, float eps, float *xn_out, float *y, void *yb, int N, int B, int act,
+                              void *stream);
 /* ---- batched decode step kernels (csrc/gemm_decode.hpp; replace the same nn.Linear calls as ma_op_gemv when B rows step
  * together, meshanything.py:143-162 with batch > 1).  All pointers device.
  * ma_op_gemm_dec: Y[B,N] = act(Xb[B,K] . W[N,K]^T + bias) + res on the bf16 matrix cores; W, Xb bf16; y fp32 and / or yb bf16

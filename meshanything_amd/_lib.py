@@ -80,6 +80,7 @@ SIGNATURES = {
     "ma_profile_decode": (_I, [_P, _I, _I, C.POINTER(KernelTiming), _P]),
     "ma_trace_decode": (_I, [_P, _I, _P, _I, _I, _P, _P, C.POINTER(C.c_int32), _P]),
     "ma_op_gemm_dec": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "ma_op_gemm_dec_ln": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _P]),
     "ma_op_gemm_dec_qkv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_size_t, _P]),
     "ma_op_rows_prologue": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _P]),
     "ma_engine_persist_available": (_I, [_P]),

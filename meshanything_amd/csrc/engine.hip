@@ -105,6 +105,8 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
+    int opt_mfma_fold_ln = 1;            // MFMA decode path, small batches: LayerNorm prologues inside the consuming GEMMs (up to two launches fewer per layer)
+    int opt_mfma_fold_fc1_max = 8, opt_mfma_fold_qkv_max = 8;       // largest batch for which LN1 (in front of fc1) / LN2 (in front of q/k/v) is folded
     int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
     int opt_attn_final_waves = 0;        // waves per block of that form: 0 = 4 from 12 rows on, 8 below; or 4 | 8 | 16
     int opt_fuse_layer = 0;              // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp)
@@ -351,6 +353,11 @@ void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, ProIn in, cons
     hipError_t r = launch_rows_prologue(a, pro, rw.B, s);
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_prologue launch failed: ") + hipGetErrorString(r));
 }
+void gemm_dec_ln(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
+    if (!tm.on(0)) return;
+    hipError_t r = launch_gemm_dec_ln(a, s);
+    if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec_ln launch failed: ") + hipGetErrorString(r));
+}
 void gemm_dec(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
     if (!tm.on(0)) return;
     hipError_t r = launch_gemm_dec(a, s);
@@ -373,9 +380,17 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     (void)MB;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     const int ks_o = gemm_dec_ksplit(H, H), ks_f = gemm_dec_ksplit(H, c.ffn);
+    // 4..16 rows: the LayerNorm prologues run inside the consuming GEMMs (gemm_dec_ln_kernel) and out_proj is not split along K, so
+    // that its epilogue finishes y1: two launches fewer per layer
+    // (the folded prologue reads its inputs once per block: 1 buffer in front of fc1, 4 split-K partials + residual in front of q/k/v, so
+    //  the second stops paying earlier: profiles/r02_ab_batched_ln_fold.txt)
+    const bool fold1 = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_fc1_max && B <= 16 && H == 1024;      // LN1 inside fc1
+    const bool fold = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_qkv_max && B <= 16 && H == 1024;       // LN2 inside q/k/v
+    const int ks_o_eff = fold1 ? 1 : ks_o;
     for (int l = 0; l < L; ++l) {
         const DecLayerPtrs& w = e->dl[l];
         const float* resid;
+        ProIn qin;                                              // input of this layer's q/k/v GEMM when its LayerNorm is folded
         if (l == 0) {
             ProIn in; in.x = x_embed;
             rows_prologue(e, s, PRO_PLAIN, rw, in, nullptr, nullptr, nullptr, tm);
@@ -383,14 +398,19 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         } else {
             ProIn in;
             if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[l - 1].fc2_b; in.res = h1; } else in.x = y2;
-            rows_prologue(e, s, PRO_LN, rw, in, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, h0, tm);
+            if (fold) qin = in;
+            else rows_prologue(e, s, PRO_LN, rw, in, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, h0, tm);
             resid = h0;
         }
         {
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1;
             a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
-            gemm_dec(e, s, a, tm);
+            if (fold && l > 0) {
+                a.pin = qin.x; a.pin_stride = H; a.pin_parts = qin.nparts; a.pbias = qin.bias; a.pres = qin.res; a.pres_stride = H;
+                a.ln_g = e->dl[l - 1].ln2_g; a.ln_b = e->dl[l - 1].ln2_b; a.ln_eps = 1e-5f; a.xn_out = h0; a.xn_stride = H;
+                gemm_dec_ln(e, s, a, tm);
+            } else gemm_dec(e, s, a, tm);
         }
         // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
         // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
@@ -409,20 +429,22 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         }
         {   // y1 = resid + Wo a + bo
             GemmDecArgs a{};
-            a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.xb = xb; a.xb_stride = H; a.N = H; a.K = H; a.B = B; a.ksplit = ks_o; a.y_stride = H;
-            if (ks_o > 1) a.y = partO; else { a.y = y1; a.bias = w.o_b; a.res = resid; a.res_stride = H; }
+            a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.xb = xb; a.xb_stride = H; a.N = H; a.K = H; a.B = B; a.ksplit = ks_o_eff; a.y_stride = H;
+            if (ks_o_eff > 1) a.y = partO; else { a.y = y1; a.bias = w.o_b; a.res = resid; a.res_stride = H; }
             gemm_dec(e, s, a, tm);
         }
-        {
-            ProIn in;
-            if (ks_o > 1) { in.x = partO; in.nparts = ks_o; in.bias = w.o_b; in.res = resid; } else in.x = y1;
-            rows_prologue(e, s, PRO_LN, rw, in, w.ln1_g, w.ln1_b, h1, tm);
-        }
+        ProIn in1;
+        if (ks_o_eff > 1) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
+        if (!fold1) rows_prologue(e, s, PRO_LN, rw, in1, w.ln1_g, w.ln1_b, h1, tm);
         {
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.fc1_w); a.bias = w.fc1_b; a.xb = xb; a.xb_stride = H; a.yb = ffb; a.yb_stride = c.ffn; a.N = c.ffn; a.K = H; a.B = B; a.ksplit = 1;
             a.act = ACT_RELU;
-            gemm_dec(e, s, a, tm);
+            if (fold1) {
+                a.pin = in1.x; a.pin_stride = H; a.pin_parts = in1.nparts; a.pbias = in1.bias; a.pres = in1.res; a.pres_stride = H;
+                a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = h1; a.xn_stride = H;
+                gemm_dec_ln(e, s, a, tm);
+            } else gemm_dec(e, s, a, tm);
         }
         {   // y2 = h1 + W2 f + b2
             GemmDecArgs a{};
@@ -1097,6 +1119,9 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "mfma_min_batch") { e->opt_mfma_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
+        else if (n == "mfma_fold_ln") { e->opt_mfma_fold_ln = (int)value; drop_graphs(e); }
+        else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
+        else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
         else if (n == "fuse_fc2") { e->opt_fuse_fc2 = (int)value; drop_graphs(e); }
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
@@ -1138,6 +1163,9 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
+        else if (n == "mfma_fold_ln") *value = e->opt_mfma_fold_ln;
+        else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
+        else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
         else if (n == "fuse_fc2") *value = e->opt_fuse_fc2;
         else if (n == "fuse_layer") *value = fuse_layer(e) ? 1 : 0;
@@ -1494,6 +1522,20 @@ int ma_op_gemm_dec(const void* W, const float* bias, const void* xb, const float
         a.N = N; a.K = K; a.B = B; a.act = act; a.epi = EPI_PLAIN; a.ksplit = ksplit;
         hipError_t r = launch_gemm_dec(a, reinterpret_cast<hipStream_t>(stream));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_dec: ") + hipGetErrorString(r));
+    });
+}
+
+int ma_op_gemm_dec_ln(const void* W, const float* bias, const float* pin, int parts, const float* pbias, const float* pres, const float* ln_g,
+                      const float* ln_b, float eps, float* xn_out, float* y, void* yb, int N, int B, int act, void* stream) {
+    return guarded(nullptr, [&] {
+        if (!W || !pin || !ln_g || !ln_b || (!y && !yb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_dec_ln: null pointer");
+        GemmDecArgs a{};
+        a.W = reinterpret_cast<const bf16_t*>(W); a.bias = bias; a.y = y; a.y_stride = N; a.yb = reinterpret_cast<bf16_t*>(yb); a.yb_stride = N;
+        a.N = N; a.K = 1024; a.B = B; a.act = act; a.epi = EPI_PLAIN; a.ksplit = 1;
+        a.pin = pin; a.pin_stride = 1024; a.pin_parts = parts; a.pbias = pbias; a.pres = pres; a.pres_stride = 1024;
+        a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.xn_out = xn_out; a.xn_stride = 1024;
+        hipError_t r = launch_gemm_dec_ln(a, reinterpret_cast<hipStream_t>(stream));
+        if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_dec_ln: ") + hipGetErrorString(r));
     });
 }
 

@@ -37,6 +37,11 @@ struct GemmDecArgs {
     int ksplit;                          // grid.y: blocks along K (1 = whole K in one block, epilogue applied here)
     void* kcache; void* vcache; size_t kv_row_stride; int H; int max_seq;
     const DecState* st;
+    // gemm_dec_ln_kernel (B <= 16, K = 1024): the LayerNorm prologue of rows_prologue_kernel<PRO_LN> inside the GEMM -- xb is not read;
+    // the activation rows are LN(sum of pin_parts partial buffers [parts][B][pin_stride] + pbias + pres), kept in LDS as bf16
+    const float* pin; int pin_stride; int pin_parts; const float* pbias; const float* pres; int pres_stride;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    float* xn_out; int xn_stride;        // LN output fp32 (a later residual), written by block (0, 0); may be null
 };
 
 template <int MT, int CH>
@@ -115,6 +120,133 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
             if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = f2bf(x);
         }
     }
+}
+
+// Small batches (B <= 16: one MFMA batch tile): the per-row LayerNorm prologue runs INSIDE the consuming GEMM instead of in a launch
+// of its own (a decode step of 4-16 rows is launch-latency bound: 5 us per dependent launch).  Every block normalises all B rows itself
+// -- one wave per row, rows w, w + 4, ...: sum of the producer's partial buffers in their fixed order + bias + residual, one-pass
+// shifted statistics (common.hpp), wave-level reduction -- and parks them in LDS as bf16 (row stride padded by 32 bytes: the 16 rows
+// of an MFMA B fragment land in different banks).  The weight rows of the block (its whole K range: 8 loads per lane) are requested
+// before the prologue.  Same MFMA mapping and epilogues as gemm_dec_kernel.  K = 1024 (the hidden size).
+__global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
+    constexpr int K = 1024, CH = 8, XS = K + 16;             // XS: LDS row stride in bf16 elements (32 bytes of padding: conflict-free fragments)
+    __shared__ __attribute__((aligned(16))) float red[4][64][4];
+    __shared__ __attribute__((aligned(16))) bf16_t xl[16 * XS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kbase = w * 256 + kg * 8;
+    const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + kbase;
+    u32x4 wv[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) wv[s] = ld_stream16(wrow + s * 32);
+    asm volatile("" ::: "memory");
+
+    // ---- prologue: rows w, w + 4, ...; two rows per pass so that the second row's loads fly under the first row's arithmetic -------------
+    const bool writer = blockIdx.x == 0 && a.xn_out;
+    auto load_row = [&](int r, f32x4 (&xv)[4], float& x0) {          // sum of the partial buffers in their order, + bias, + residual
+        const float* x = a.pin + (size_t)r * a.pin_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(x + (lane + 64 * j) * 4);
+        x0 = x[0];
+        for (int p = 1; p < a.pin_parts; ++p) {
+            const float* xp = x + (size_t)p * a.B * a.pin_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            x0 += xp[0];
+        }
+        if (a.pbias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.pbias + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            x0 += a.pbias[0];
+        }
+        if (a.pres) {
+            const float* rp = a.pres + (size_t)r * a.pres_stride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            x0 += rp[0];
+        }
+    };
+    auto finish_row = [&](int r, f32x4 (&xv)[4], float x0) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ln_chunk_moments(xv[j], x0, sm, sq);
+        sm = wave_sum(sm); sq = wave_sum(sq);
+        float md, rstd;
+        ln_finish(sm, 0.f, 0.f, 0.f, sq, 0.f, 0.f, 0.f, K, a.ln_eps, md, rstd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = (lane + 64 * j) * 4;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + idx), bb = *reinterpret_cast<const f32x4*>(a.ln_b + idx);
+            ln_apply(xv[j], md, rstd, g, bb);
+            if (writer) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)r * a.xn_stride + idx) = xv[j];
+            u32x2 pk;
+            pk.x = (uint32_t)f2bf(xv[j].x) | ((uint32_t)f2bf(xv[j].y) << 16);
+            pk.y = (uint32_t)f2bf(xv[j].z) | ((uint32_t)f2bf(xv[j].w) << 16);
+            *reinterpret_cast<u32x2*>(&xl[r * XS + idx]) = pk;
+        }
+    };
+    for (int r = w; r < a.B; r += 8) {
+        f32x4 xa[4], xb2[4];
+        float x0a, x0b = 0.f;
+        const bool two = r + 4 < a.B;
+        load_row(r, xa, x0a);
+        if (two) load_row(r + 4, xb2, x0b);
+        finish_row(r, xa, x0a);
+        if (two) finish_row(r + 4, xb2, x0b);
+    }
+    __syncthreads();
+
+    // ---- MFMA: A = the block's 16 weight rows, B = the 16 (<= B valid) activation rows from LDS ---------------------------------------
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xr = xl + min(m, a.B - 1) * XS + kbase;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(xr + s * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv), acc, 0, 0, 0);
+    }
+    *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][lane][0]);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const int b = m;
+    if (b >= a.B) return;
+    const int r0 = n0 + kg * 4;
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const int pos = a.epi == EPI_QKV ? a.st[b].pos : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = r0 + r;
+        if (n >= a.N) continue;
+        float x = o[r];
+        if (a.bias) x += a.bias[n];
+        x = apply_act(x, a.act);
+        if (a.res) x += a.res[(size_t)b * a.res_stride + n];
+        if (a.epi == EPI_QKV) {
+            const int part = n / a.H, c = n - part * a.H;
+            if (part == 0) a.y[(size_t)b * a.y_stride + c] = x;
+            else {
+                const int head = c >> 6, d = c & 63;
+                const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
+                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = f2bf(x);
+            }
+        } else {
+            if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
+            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = f2bf(x);
+        }
+    }
+}
+
+inline hipError_t launch_gemm_dec_ln(const GemmDecArgs& a, hipStream_t s) {
+    if (a.K != 1024 || a.B < 1 || a.B > 16 || a.ksplit != 1 || !a.pin || a.pin_parts < 1 || !a.ln_g || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) ||
+        (a.xn_out && a.xn_stride % 4)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_dec_ln_kernel, dim3((a.N + 15) / 16), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 // K split over blocks for matrices with few row tiles (every CU should stream): up to 4 when N <= 2048 and K allows it

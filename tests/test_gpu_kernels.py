@@ -238,6 +238,46 @@ def test_decode_attention_rows(lib, B, length, H, waves):
 
 
 # ---------------------------------------------------------------------------------------------- batched decode step kernels
+@pytest.mark.parametrize("B", [1, 4, 8, 13, 16])
+@pytest.mark.parametrize("N,parts,act,extras", [(3072, 4, 0, True), (4096, 1, 1, True), (4096, 1, 1, False), (1024, 2, 0, True), (8195, 4, 0, True)])
+def test_gemm_dec_ln(lib, B, N, parts, act, extras):
+    """Skinny GEMM with the LayerNorm prologue inside (small batches of the batched decode step): activation row = LN(sum of the
+    partial buffers + bias + residual) rounded to bf16; against fp64 torch on the same rounding point; the LayerNorm output itself
+    (the later residual) within fp32 accuracy; bit-stable across launches."""
+    K = 1024
+    g = torch.Generator().manual_seed(B + N + parts)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    pin = torch.randn(parts, B, K, generator=g) * 0.7 + 3.0            # a large common offset: the shifted statistics must cope
+    pb = torch.randn(K, generator=g) * 0.1 if extras else None
+    pr = torch.randn(B, K, generator=g) if extras else None
+    lg, lb = 1.0 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    bias = torch.randn(N, generator=g) * 0.1
+    x = pin.double().sum(dim=0)
+    if extras:
+        x = x + pb.double() + pr.double()
+    xn = torch.nn.functional.layer_norm(x, (K,), lg.double(), lb.double(), 1e-5)
+    dev = "cuda"
+    d = lambda t: None if t is None else t.to(dev).contiguous()
+    Wd, pind, pbd, prd, lgd, lbd, bd = d(W), d(pin), d(pb), d(pr), d(lg), d(lb), d(bias)
+    outs = []
+    for it in range(2):
+        y = torch.full((B, N), float("nan"), device=dev)
+        yb = torch.zeros(B, N, dtype=torch.bfloat16, device=dev)
+        xo = torch.full((B, K), float("nan"), device=dev)
+        _chk(lib, lib.ma_op_gemm_dec_ln(_p(Wd), _p(bd), _p(pind), parts, _p(pbd), _p(prd), _p(lgd), _p(lbd), 1e-5, _p(xo), _p(y), _p(yb), N, B, act, _stream()))
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), yb.cpu(), xo.cpu()))
+    y, yb, xo = outs[0]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert float((xo.double() - xn).abs().max()) < 2e-5
+    ref = xo.to(torch.bfloat16).double() @ W.double().t() + bias.double()   # the kernel's own LayerNorm output, rounded where the kernel rounds
+    if act == 1:
+        ref = torch.relu(ref)
+    assert not torch.isnan(y).any()
+    assert _relerr(y, ref.float()) < 2e-5, _relerr(y, ref.float())
+    assert torch.equal(yb, y.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("B", [4, 16, 17, 40, 64])
 @pytest.mark.parametrize("N,K,ksplit,act", [(3072, 1024, 1, 0), (4096, 1024, 1, 1), (1024, 1024, 4, 0), (1024, 4096, 4, 0), (1024, 4096, 1, 0),
                                            (8195, 1024, 1, 0), (384, 128, 1, 1), (128, 512, 4, 0)])
