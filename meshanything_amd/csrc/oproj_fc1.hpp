@@ -1,16 +1,22 @@
-// Fused out_proj (+ merge of the split-KV partials) + LayerNorm + fc1 of one layer, batch-1 launch chain (bf16 policy,
-// hidden 1024, ffn 4096).
+// Second half of a decoder layer in one launch, batch-1 launch chain (bf16 policy, hidden 1024, ffn 4096): merge of the split-KV
+// partials + out_proj + residual, LayerNorm 1, fc1 + ReLU and (template FC2, the default) fc2 + residual.
 //
-// Replaces two launches of the chain ([3p] OPTDecoderLayer: out_proj + residual, self_attn_layer_norm, fc1 + ReLU; reached from
-// shape_opt.py:403-410): both run on 256 blocks already (out_proj: 4 rows per block, fc1: 16 rows per block), so block b of the
-// fused launch does exactly the work of block b of either.  The dependency between them -- every fc1 row needs all 1024 values of
-// y1 = h + Wo a + bo -- is an all-gather of 1024 fp32 values, done inside the launch with tagged granules (MI355X guide, Guideline
-// 16 R2; measured 2.0 us per sweep in the persistent step, profiles/r02_persist_v3_timeline.txt) instead of a kernel boundary +
-// launch ramp + a dependent reload of the vector and its LayerNorm parameters (3.4 us).  Everything that does not depend on the
-// exchange is issued in the first instructions: the attention partials, the out_proj row, the 4 fc1 rows (32 KB per block), biases,
-// LayerNorm parameters.  The arithmetic is gemv_kernel's ({1, 2, 1} and {1, 2, 4} shapes), bit for bit.
-// Epoch = position * 32 + layer + 1 (buffer zeroed when the position restarts); the sweep is bounded (20 ms) and raises the
-// engine's error word instead of hanging; all 256 (x batch) blocks must be resident.
+// Replaces three launches of the five-launch chain ([3p] OPTDecoderLayer: out_proj + residual, self_attn_layer_norm, fc1 + ReLU, fc2 +
+// residual; reached from shape_opt.py:403-410): all run on 256 blocks (out_proj and fc2: 4 rows per block, fc1: 16 rows per block), so
+// block b of the fused launch does exactly the work of block b of each.  The dependencies between them -- every fc1 row needs all
+// 1024 values of y1 = h + Wo a + bo, every fc2 row all 4096 values of relu(fc1) -- are all-gathers done inside the launch with
+// tagged granules (MI355X guide, Guideline 16 R2) instead of a kernel boundary + launch ramp + a dependent reload of the vector:
+//   * y1: one 8-byte {epoch, fp32} granule per wave out, the four waves sweep a quarter of the 1024 each;
+//   * relu(fc1): fc2 consumes it rounded to bf16, so a granule carries two values ({epoch, bf16, bf16}): 2048 granules, a quarter
+//     per wave.
+// What such an exchange costs is its polling (profiles/r02_ab_exchange_and_load_placement.txt): one wave sweeping all of y1 took
+// 2.2 us, four waves a quarter each 4 % of the step less; relu(fc1) with one value per granule 4 % more than with two.
+// The attention partials, the out_proj row, the 4 fc1 rows (32 KB per block), biases and LayerNorm parameters are requested in the first
+// instructions, the fc2 row under the first exchange.  The arithmetic is gemv_kernel's ({1, 2, 1}, {1, 2, 4}, {1, 8, 1} shapes), bit
+// for bit (tests/test_gpu_persist.py).
+// Epoch = position * 32 + layer + 1 (buffers zeroed when the position restarts); sweeps are bounded (20 ms) and raise the engine's
+// error word instead of hanging; all 256 blocks of a batch row must be resident together (checked at engine creation).
+// The body is a device function so that layer_fused.hpp can continue with the next layer's first half in the same launch.
 #pragma once
 #include "attn_decode.hpp"
 #include "common.hpp"

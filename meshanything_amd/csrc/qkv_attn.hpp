@@ -4,8 +4,9 @@
 // shape_opt.py:403-410) and the split-KV attention (attn_decode.hpp; [3p] OptFlashAttention2 + the per-step torch.cat) -- by one:
 // attention of head h needs only the 192 q/k/v outputs of head h, so the exchange between the two is not all-to-all.  Block
 // (chunk c, head h) of the 16 x heads grid
-//   1. issues, in its first instructions: the input vector + LayerNorm parameters, its 12 weight rows (q, k, v rows
-//      64 h + 4 c + wave of the fused [3H][H] matrix: 24 KB), and round 0 of its K / V cache rows (they depend on nothing);
+//   1. issues, in its first instructions: the input vector + LayerNorm parameters and its 12 weight rows (q, k, v rows
+//      64 h + 4 c + wave of the fused [3H][H] matrix: 24 KB) -- NOT yet the cache rows: they would compete with these on the way to
+//      the publish (step 3) and are requested right after it, riding under the exchange (-2 % per step, measured);
 //   2. runs the GEMV prologue (LayerNorm of the post-LN stream, common.hpp) and its 12 dot products -- the arithmetic of
 //      gemv_kernel<bf16, 1, 2, *, *>, bit for bit;
 //   3. publishes the 12 values as 8-byte {epoch, value} granules (one sc1 store each; MI355X guide, Guideline 16 R2) and one
@@ -14,7 +15,7 @@
 //      increasing within a generation, the buffer is zeroed when the position restarts;
 //   4. attends over its chunk with the shared round / merge code of attn_decode.hpp (the newest position's K / V rows come from the
 //      granules, and are written to the cache for later steps) and writes the (m, l, o[64]) partial for the out_proj launch.
-// One launch boundary and one dependent-vector round trip less per layer; the K / V stream is in flight while q is computed.
+// One launch boundary and one dependent-vector round trip less per layer; the K / V stream is in flight during the exchange.
 // Every block of the grid must be resident (256 x batch blocks of 256 threads: any device with >= 32 CUs); the sweep is bounded
 // (20 ms) and raises the engine's error word instead of hanging.
 #pragma once
