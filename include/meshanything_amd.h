@@ -215,7 +215,8 @@ MA_API size_t ma_decode_attention_workspace_bytes(int H);
  * over all `len` cached positions, output already normalised and rounded: out = bf16 [B][H*64].  q fp32 [B][H*64]; row b's cache planes start at b * kv_row_stride elements
  * (bf16, each (H, max_seq, 64)).  Replaces [3p] flash_attn_func(q_len = 1) for a batch (meshanything.py:143-162 batch semantics). */
 MA_API int  ma_op_decode_attention_rows(const float *q, const void *kcache, const void *vcache, int H, int max_seq, int len, int B,
-                                        size_t kv_row_stride, int waves, void *out, void *stream);
+                                        size_t kv_row_stride, int waves, int halves /* 1 | 2: blocks per (row, head); 2 = in-launch hand-over, 8 waves */,
+                                        void *out, void *stream);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
 /* Time the decode step with HIP events on `stream` at KV length `kv_len` (cache contents arbitrary): `steps` back-to-back

@@ -75,7 +75,7 @@ SIGNATURES = {
     "ma_op_layernorm": (_I, [_P, _I, _P, _P, _F, _P, _I, _I, _I, _P]),
     "ma_op_attention": (_I, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "ma_op_decode_attention": (_I, [_I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
-    "ma_op_decode_attention_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_size_t, _I, _P, _P]),
+    "ma_op_decode_attention_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, C.c_size_t, _I, _I, _P, _P]),
     "ma_decode_attention_workspace_bytes": (C.c_size_t, [_I]),
     "ma_profile_decode": (_I, [_P, _I, _I, C.POINTER(KernelTiming), _P]),
     "ma_trace_decode": (_I, [_P, _I, _P, _I, _I, _P, _P, C.POINTER(C.c_int32), _P]),

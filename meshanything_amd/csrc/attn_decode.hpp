@@ -299,10 +299,17 @@ inline hipError_t launch_attn_decode(const float* q, const void* kc, const void*
 // q_len 1, one call per layer).  NW = 4 from 12 rows on (>= 192 blocks); 8 <= rows < 12 give 128-176 blocks, which stream
 // with NW = 8 waves each; below 8 rows the split form wins (too few blocks).  Same per-slot arithmetic
 // (attn_round_reduce) as the split form; only the grouping of positions into partial states differs.
-template <typename KT, int NW>
+// SPLIT2 (8..11 rows: 128-176 (row, head) pairs leave half of the CUs without a block): TWO blocks per pair, each over half of the
+// rounds; block z = 0 hands its (m, l, o[64]) to block z = 1 inside the launch as 66 tagged 8-byte granules (the protocol of the
+// batch-1 chain, qkv_attn.hpp: epoch = position * 32 + layer + 1, bounded sweep, error word), which merges the two states in a fixed
+// order and writes the output.  The publishing blocks are dispatched first and never wait.
+constexpr int ATTN_PAIR_GRANULES = 72;                   // 64 x o + m + l, padded
+constexpr unsigned ATTN_ERR_PAIR = 64;
+template <typename KT, int NW, bool SPLIT2>
 __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float* __restrict__ q, const KT* __restrict__ kc, const KT* __restrict__ vc,
                                                                     int max_seq, const DecState* st, int len_override, int round_q,
-                                                                    bf16_t* __restrict__ out, int out_stride, int q_stride, size_t kv_row_stride) {
+                                                                    bf16_t* __restrict__ out, int out_stride, int q_stride, size_t kv_row_stride,
+                                                                    unsigned long long* pair_gran, unsigned* err, int layer) {
     using G = AttnGeom<KT>;
     constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, U = G::U;
     constexpr int RPOS = NW * 32;                           // positions per round of the block
@@ -322,12 +329,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
         }
     }
     const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
-    const int nround = (max(end, 0) + RPOS - 1) / RPOS;
+    const int nr_all = (max(end, 0) + RPOS - 1) / RPOS;
+    // SPLIT2: the publisher (z = 0) takes the upper ceil(n / 2) rounds, the merging block the lower floor(n / 2)
+    const int rbeg = SPLIT2 ? (blockIdx.z == 0 ? nr_all / 2 : 0) : 0;
+    const int nround = SPLIT2 ? (blockIdx.z == 0 ? nr_all - nr_all / 2 : nr_all / 2) : nr_all;
     const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
     const KT* vh = vc + (size_t)h * max_seq * 64 + dsub * EPL;
     u32x4 kA[U], vA[U], kB[U], vB[U];
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
-        const int base = r * RPOS + w * 32 + slot;
+        const int base = (rbeg + r) * RPOS + w * 32 + slot;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = base + u * PPW;
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
     for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
     const u32x4 none = {0u, 0u, 0u, 0u};
     auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
-        attn_round_reduce<KT, false>(ss, qv, kr, vr, r * RPOS + w * 32 + slot, end, -1, none, none);
+        attn_round_reduce<KT, false>(ss, qv, kr, vr, (rbeg + r) * RPOS + w * 32 + slot, end, -1, none, none);
     };
     if (round_q) {
 #pragma unroll
@@ -395,6 +405,35 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
             L = fmaf(wl_[i], f, L);
             O = fmaf(wo_[i][lane], f, O);
         }
+        if constexpr (SPLIT2) {
+            typedef __attribute__((address_space(1))) unsigned long long gull;
+            gull* g = (gull*)(pair_gran + ((size_t)brow * gridDim.x + h) * ATTN_PAIR_GRANULES);
+            const unsigned epoch = (unsigned)(end - 1) * 32u + (unsigned)layer + 1u;
+            if (blockIdx.z == 0) {                           // publisher: 64 x o, then m and l
+                __hip_atomic_store(g + lane, ((unsigned long long)epoch << 32) | __float_as_uint(O), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < 2) __hip_atomic_store(g + 64 + lane, ((unsigned long long)epoch << 32) | __float_as_uint(lane == 0 ? M : L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            unsigned long long vo = 0, vm = (unsigned long long)epoch << 32;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            for (;;) {
+                vo = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < 2) vm = __hip_atomic_load(g + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(vo >> 32) == epoch && (unsigned)(vm >> 32) == epoch)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {      // 20 ms of the 100 MHz counter
+                    if (lane == 0) __hip_atomic_fetch_or(err, ATTN_ERR_PAIR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vo = 0; vm = 0;
+                    break;
+                }
+            }
+            const float O2 = __uint_as_float((unsigned)vo);
+            const float M2 = __shfl(__uint_as_float((unsigned)vm), 0, 64), L2 = __shfl(__uint_as_float((unsigned)vm), 1, 64);
+            const float Mx = fmaxf(M, M2), f1 = expf(M - Mx), f2 = expf(M2 - Mx);      // this block's (lower) half first, then the partner's
+            L = fmaf(L2, f2, L * f1);
+            O = fmaf(O2, f2, O * f1);
+        }
         out[(size_t)brow * out_stride + h * 64 + lane] = f2bf(O * (1.0f / L));     // position 0 always exists: L > 0
     }
 }
@@ -402,12 +441,18 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
 template <typename KT>
 inline hipError_t launch_attn_decode_final(const float* q, const void* kc, const void* vc, int H, int max_seq, const DecState* st, int len_override,
                                            int round_q, bf16_t* out, int out_stride, hipStream_t s, int batch, int q_stride, size_t kv_row_stride,
-                                           int waves = 0) {
+                                           int waves = 0, unsigned long long* pair_gran = nullptr, unsigned* err = nullptr, int layer = 0) {
     if (waves == 0) waves = batch >= 12 ? 4 : 8;          // measured: profiles/r02_ab_batched_attention_forms.txt
     const KT* k = reinterpret_cast<const KT*>(kc); const KT* v = reinterpret_cast<const KT*>(vc);
-    if (waves == 4) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 4>), dim3(H, batch), dim3(256), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
-    else if (waves == 8) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 8>), dim3(H, batch), dim3(512), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
-    else if (waves == 16) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 16>), dim3(H, batch), dim3(1024), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride);
+    if (pair_gran) {                                       // two blocks per (row, head), 8 waves each
+        if (!err || waves != 8) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((attn_decode_final_kernel<KT, 8, true>), dim3(H, batch, 2), dim3(512), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride, pair_gran, err, layer);
+        return hipGetLastError();
+    }
+    unsigned long long* ng = nullptr; unsigned* ne = nullptr;
+    if (waves == 4) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 4, false>), dim3(H, batch), dim3(256), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride, ng, ne, 0);
+    else if (waves == 8) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 8, false>), dim3(H, batch), dim3(512), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride, ng, ne, 0);
+    else if (waves == 16) hipLaunchKernelGGL((attn_decode_final_kernel<KT, 16, false>), dim3(H, batch), dim3(1024), 0, s, q, k, v, max_seq, st, len_override, round_q, out, out_stride, q_stride, kv_row_stride, ng, ne, 0);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -105,6 +105,7 @@ struct ma_engine {
     int opt_prefill_stepwise = 0;    // 1: run the prefix through the decode-step chain row by row (debug cross-check)
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
+    int opt_attn_pair = 1;               // final-form attention below 12 rows: two blocks per (row, head)
     int opt_mfma_fold_ln = 1;            // MFMA decode path, small batches: LayerNorm prologues inside the consuming GEMMs (up to two launches fewer per layer)
     int opt_mfma_fold_fc1_max = 8, opt_mfma_fold_qkv_max = 8;       // largest batch for which LN1 (in front of fc1) / LN2 (in front of q/k/v) is folded
     int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
@@ -119,6 +120,7 @@ struct ma_engine {
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
+    unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     u64* d_y2_gran = nullptr;        // [max_batch][hidden] granules (y2 handed to the next layer inside a launch)
     u64* d_ffn_gran = nullptr;       // [max_batch][ffn] granules (fc2 in the out_proj + fc1 launch)
     unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
@@ -414,10 +416,15 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         }
         // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
         // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
-        if (B >= e->opt_attn_final_min_batch && (B >= 12 || e->maxseq <= 8192)) {
+        // the pair form needs both blocks of every (row, head) resident together: 2 B heads <= CUs (8 rows on an MI355X)
+        const bool pair_ok = e->opt_attn_pair && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
+        if (B >= e->opt_attn_final_min_batch && (B >= 12 || pair_ok || e->maxseq <= 8192)) {
             // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
             if (tm.on(1)) {
-                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems, e->opt_attn_final_waves);
+                // 8..11 rows: two blocks per (row, head) with an in-launch hand-over, so that every CU streams (attn_decode.hpp)
+                const bool pair = pair_ok && B < 12;
+                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems,
+                                                                pair ? 8 : e->opt_attn_final_waves, pair ? e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES : nullptr, e->d_chain_err, l);
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode_final launch failed: ") + hipGetErrorString(r));
             }
         } else {
@@ -649,7 +656,6 @@ void check_persist_error(ma_engine* e, hipStream_t s) {
 
 // the fused q/k/v + attention launch reports an expired (bounded) granule sweep through a device word
 void check_chain_error(ma_engine* e, hipStream_t s) {
-    if (!fuse_qkv_attn(e) && !fuse_oproj_fc1(e)) return;
     HIP_CHECK(hipMemcpyAsync(e->h_chain_err, e->d_chain_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (*e->h_chain_err) {
@@ -792,6 +798,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipMemsetAsync(e->d_qkv_gran, 0, (size_t)e->cfg.max_batch * 3 * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_y1_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_ffn_gran, 0, (size_t)e->cfg.max_batch * e->cfg.ffn * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_attn_pair_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_PAIR_GRANULES * sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(e->d_y2_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
 }
 
@@ -962,6 +969,8 @@ void build_engine(ma_engine* e) {
     e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(1);
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
+    e->d_attn_pair_gran = e->dmalloc<unsigned long long>(MB * c.heads * ATTN_PAIR_GRANULES);
+    HIP_CHECK(hipMemset(e->d_attn_pair_gran, 0, MB * c.heads * ATTN_PAIR_GRANULES * sizeof(unsigned long long)));
     e->d_y2_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y2_gran, 0, MB * H * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
@@ -1120,6 +1129,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_ln") { e->opt_mfma_fold_ln = (int)value; drop_graphs(e); }
+        else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
@@ -1164,6 +1174,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else if (n == "mfma_fold_ln") *value = e->opt_mfma_fold_ln;
+        else if (n == "attn_pair") *value = e->opt_attn_pair;
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
@@ -1502,12 +1513,26 @@ int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, cons
 // batched single-query attention, final form (attn_decode_final_kernel): B rows, each its own cache plane, all of length `len`;
 // out = bf16 [B][H * 64]
 int ma_op_decode_attention_rows(const float* q, const void* kcache, const void* vcache, int H, int max_seq, int len, int B, size_t kv_row_stride,
-                                int waves, void* out, void* stream) {
+                                int waves, int halves, void* out, void* stream) {
     return guarded(nullptr, [&] {
         if (!q || !kcache || !vcache || !out || H < 1 || B < 1 || len < 1 || len > max_seq || kv_row_stride < (size_t)H * max_seq * 64)
             throw MaError(MA_ERR_INVALID, "ma_op_decode_attention_rows: bad arguments");
-        HIP_CHECK(launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64,
-                                                   reinterpret_cast<hipStream_t>(stream), B, H * 64, kv_row_stride, waves));
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        if (halves == 2) {                                   // two blocks per (row, head): scratch granules + error word for this call
+            unsigned long long* g = nullptr; unsigned* er = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g), (size_t)B * H * ATTN_PAIR_GRANULES * sizeof(unsigned long long) + 64));
+            er = reinterpret_cast<unsigned*>(g + (size_t)B * H * ATTN_PAIR_GRANULES);
+            (void)hipMemsetAsync(g, 0, (size_t)B * H * ATTN_PAIR_GRANULES * sizeof(unsigned long long) + 64, s);
+            hipError_t r = launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, 8, g, er, 3);
+            unsigned herr = 0;
+            (void)hipMemcpyAsync(&herr, er, sizeof(unsigned), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(g);
+            HIP_CHECK(r);
+            if (herr) throw MaError(MA_ERR_HIP, "ma_op_decode_attention_rows: the hand-over between the two blocks of a pair timed out");
+        } else if (halves == 1 || halves == 0) {
+            HIP_CHECK(launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, waves));
+        } else throw MaError(MA_ERR_INVALID, "ma_op_decode_attention_rows: halves must be 1 or 2");
     });
 }
 
