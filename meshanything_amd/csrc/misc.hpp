@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
         if (nparts > 0) {            // per-block partials of the lm_head GEMV (eos already excluded there when suppressed): reduced above
         } else {                     // batched MFMA lm_head: plain logits
             const int skip = sv.suppress_eos ? TOK_EOS : -1;
+#pragma unroll 8                                                        // the loads of 8 iterations in flight (the compare chain would serialise them)
             for (int i = tid; i < V; i += 256) { const float v = logits[i]; if (i != skip && arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
         }
 #pragma unroll
