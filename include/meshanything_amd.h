@@ -256,6 +256,12 @@ MA_API int  ma_op_rows_prologue(int pro, const float *x, int nparts, int B, cons
                                 const float *ln_b, float ln_eps, const float *attn_ws, int attn_heads, float *xn_out,
                                 void *xb_out, int K, void *stream);
 
+/* ---- test aid: holds `n_blocks` workgroups of `lds_bytes` of LDS each (163840 = a whole CU) on the device for `microseconds`
+ * (bounded: <= 2 s) on `stream`, doing nothing.  Lets a test take CUs away from the engine's stream and check that the fused decode
+ * launches -- which need their whole grid resident -- fall back to the five-launch chain instead of failing the request.  Has no
+ * reference counterpart (the reference never shares a device between streams). */
+MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, void *stream);
+
 /* ---- persistent decode step (csrc/persist.hpp): the whole batch-1 greedy step as ONE resident launch instead of the
  * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()
  * and the call is batch 1 / greedy, otherwise the chain runs.  replaces: the same reference calls as ma_generate's steps

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ma_op_gemm_dec_ln": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _P]),
     "ma_op_gemm_dec_qkv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_size_t, _P]),
     "ma_op_rows_prologue": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _P]),
+    "ma_op_occupy_cus": (_I, [_I, _I, C.c_int64, _P]),
     "ma_engine_persist_available": (_I, [_P]),
     "ma_persist_trace": (_I, [_P, _I, _P, C.POINTER(C.c_int32), _P]),
     "ma_engine_read_logits": (_I, [_P, _I, _P, _P]),
@@ -100,10 +101,17 @@ def load() -> C.CDLL:
         raise ImportError(f"{LIB_PATH} not found: the MI355X HIP library has not been built "
                           f"(run `python __graft_entry__.py` / meshanything_amd.build.build()).  There is no CPU fallback.")
     from . import build as _build
-    if _build.recorded_hash() != _build.source_hash():
-        raise ImportError(f"{LIB_PATH} was built from different sources than the ones next to it (csrc/*.hip, csrc/*.hpp or "
-                          f"include/meshanything_amd.h changed since): rebuild with `python __graft_entry__.py`.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    if _build.have_sources():            # a packaged library without csrc/ next to it has nothing to be stale against
+        have = _build.embedded_hash(LIB_PATH)
+        if have != _build.source_hash():
+            msg = (f"{LIB_PATH} was built from different sources than the ones next to it (embedded source hash {have[:12] or 'none'}, tree "
+                   f"{_build.source_hash()[:12]}: csrc/*.hip, csrc/*.hpp or include/meshanything_amd.h changed since): rebuild with "
+                   f"`python __graft_entry__.py`, or set MA_ALLOW_STALE_LIB=1 to load it anyway.")
+            if os.environ.get("MA_ALLOW_STALE_LIB", "") != "1":
+                raise ImportError(msg)
+            import warnings
+            warnings.warn(msg)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res

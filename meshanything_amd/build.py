@@ -1,14 +1,18 @@
 """Build the gfx950 HIP library in-tree (hipcc cross-compiles without a GPU).
 
 The library is rebuilt whenever the SHA-256 over every source it is compiled from (csrc/*.hip, csrc/*.hpp, the public
-header) differs from the hash recorded next to it at build time; `_lib.load()` refuses a library whose recorded hash does
-not match the tree it sits in (a stale .so would otherwise travel to the GPU box silently: it is git-ignored, not
-gpurun-ignored)."""
+header, the flags, the compiler's version line) differs from the hash compiled INTO it (`ma_version()` ends in `src=<hash>`; a
+copy is kept in a side file so that `needs_build()` does not have to dlopen).  `_lib.load()` refuses a library whose embedded
+hash does not match the tree it sits in (a stale .so would otherwise travel to the GPU box silently: it is git-ignored, not
+gpurun-ignored); a packaged library without the sources next to it is not checked, and MA_ALLOW_STALE_LIB=1 downgrades the
+refusal to a warning."""
 from __future__ import annotations
 
+import ctypes
 import glob
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -25,6 +29,10 @@ def source_files():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))) + [HEADER]
 
 
+def have_sources() -> bool:
+    return all(os.path.exists(os.path.join(CSRC, f)) for f in SOURCES) and os.path.exists(HEADER)
+
+
 def source_hash() -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
@@ -36,12 +44,23 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def embedded_hash(path: str = OUT) -> str:
+    """The source hash compiled into the library (`ma_version()`), "" if it cannot be read."""
+    try:
+        lib = ctypes.CDLL(path)
+        lib.ma_version.restype = ctypes.c_char_p
+        m = re.search(r"src=([0-9a-f]{64})", lib.ma_version().decode())
+        return m.group(1) if m else ""
+    except (OSError, AttributeError):
+        return ""
+
+
 def recorded_hash() -> str:
     try:
         with open(HASH_FILE) as f:
             return f.read().strip()
     except OSError:
-        return ""
+        return embedded_hash() if os.path.exists(OUT) else ""
 
 
 def _hipcc() -> str:
@@ -59,7 +78,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     want = source_hash()
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp", "-ldl"]
+    cmd = [_hipcc()] + FLAGS + [f'-DMA_SRC_HASH="{want}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp", "-ldl"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

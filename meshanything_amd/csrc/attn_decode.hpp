@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
                 if (lane < 2) vm = __hip_atomic_load(g + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((unsigned)(vo >> 32) == epoch && (unsigned)(vm >> 32) == epoch)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {      // 20 ms of the 100 MHz counter
+                if (xchg_expired(spins, t0, err)) {
                     if (lane == 0) __hip_atomic_fetch_or(err, ATTN_ERR_PAIR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     vo = 0; vm = 0;
                     break;

@@ -154,6 +154,28 @@ struct RowMap {
     __host__ __device__ inline size_t operator()(int r) const { return grp > 0 ? (size_t)(r / grp) * gstride + (r % grp) + off : (size_t)r; }
 };
 
+// ---- in-launch exchange between resident workgroups (MI355X guide, Guideline 16 R2) -------------------------------------------
+// A value travels as ONE naturally aligned 8-byte {epoch, payload} granule written with an agent-scope (sc1) store and polled with
+// relaxed agent-scope loads: the data is the flag, so no fence, no separate flag word and no ordering between the two are needed.
+// Used by the fused launches of the decode chain (qkv_attn.hpp, oproj_fc1.hpp, layer_fused.hpp, attn_decode.hpp's two-block form)
+// and by the persistent step (persist.hpp).
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr u64 PS_TIMEOUT_TICKS = 20ull * 100000ull;            // 20 ms of the 100 MHz real-time counter: bound of every sweep
+
+__device__ __forceinline__ void ps_publish(u64* gran, int idx, unsigned epoch, unsigned value) {
+    __hip_atomic_store((gu64*)gran + idx, ((u64)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Bounded sweep: true when the polling wave must give up -- its own deadline passed, or some block of this generation already raised
+// the engine's error word (then every later sweep gives up after at most 64 polls instead of burning its own 20 ms: a launch whose
+// blocks are not all resident costs one deadline, not one per launch).  Checked every 64th poll only: nothing on the fast path.
+__device__ __forceinline__ bool xchg_expired(unsigned& spins, u64 t0, const unsigned* err) {
+    if ((++spins & 63u) != 0) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) return true;
+    return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

@@ -47,6 +47,12 @@ struct MaError : std::exception {
     const char* what() const noexcept override { return msg.c_str(); }
 };
 
+// an in-launch exchange of a fused decode launch gave up (its blocks were not all resident): generate() answers by switching this
+// engine to the five-launch chain (no co-residency needed, same bits) and running the generation again
+struct ChainTimeout : MaError {
+    ChainTimeout(std::string m) : MaError(MA_ERR_HIP, std::move(m)) {}
+};
+
 #define HIP_CHECK(expr)                                                                                      \
     do {                                                                                                     \
         hipError_t _e = (expr);                                                                              \
@@ -66,6 +72,7 @@ struct ma_engine {
     bool weights_ready = false;
     std::string err;
     char* arena = nullptr;
+    void* stage = nullptr; size_t stage_bytes = 0;      // upload staging of ma_engine_load_weights (freed by finalize)
 
     int T = 0, V = 0, maxnew = 0, maxseq = 0, nf = 0, S = 0;
     bool bf16 = true;
@@ -128,6 +135,8 @@ struct ma_engine {
     int n_cus = 0;
     bool persist_shape = false;      // shape / device eligibility (fixed at creation)
     bool chain_resident = false;     // the fused launches' 256 blocks fit on the device at once, with margin (their in-launch exchange needs that)
+    long resident_blocks = 0;        // 256-thread blocks of the fused launches the device holds at once (CUs x (occupancy - 1))
+    int chain_fallbacks = 0;         // generations that were re-run on the five-launch chain after an exchange timed out
     bool embtab_ready = false;
     DecLayerPtrs* d_layers = nullptr;
     u64* d_gran = nullptr; unsigned* d_serial = nullptr; unsigned* d_err = nullptr; unsigned* h_err = nullptr;
@@ -417,7 +426,8 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
         // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
         // the pair form needs both blocks of every (row, head) resident together: 2 B heads <= CUs (8 rows on an MI355X)
-        const bool pair_ok = e->opt_attn_pair && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
+        // (its hand-over epoch is position * 32 + layer + 1: more than 31 layers would alias the next position's layer 0)
+        const bool pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
         if (B >= e->opt_attn_final_min_batch && (B >= 12 || pair_ok || e->maxseq <= 8192)) {
             // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
             if (tm.on(1)) {
@@ -470,8 +480,18 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     gemm_dec(e, s, g, tm);
 }
 
-bool fuse_oproj_fc1(ma_engine* e) { return e->opt_fuse_oproj_fc1 && e->chain_resident && e->bf16 && e->cfg.hidden == 1024 && e->cfg.ffn == 4096 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
-bool fuse_qkv_attn(ma_engine* e) { return e->opt_fuse_qkv_attn && e->chain_resident && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30; }
+// The fused launches spin on granules written by other blocks of the same grid, so EVERY block of the grid (256 per batch row) must
+// be resident at once: B rows are fused only while 256 B blocks fit with a quarter of margin (HIP does not promise in-order
+// dispatch, so a later row's blocks may not be assumed to wait politely); larger B, a device that turned out to be shared
+// (chain_resident cleared after a timeout), or a caller-supplied length (the exchange epochs come from DecState.pos, which
+// such a caller does not advance) take the five-launch chain.
+bool chain_fits(ma_engine* e, int B, int len_override) { return e->chain_resident && len_override < 0 && e->resident_blocks * 4 >= 256L * B * 5; }
+bool fuse_oproj_fc1(ma_engine* e, int B = 1, int len_override = -1) {
+    return e->opt_fuse_oproj_fc1 && chain_fits(e, B, len_override) && e->bf16 && e->cfg.hidden == 1024 && e->cfg.ffn == 4096 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
+}
+bool fuse_qkv_attn(ma_engine* e, int B = 1, int len_override = -1) {
+    return e->opt_fuse_qkv_attn && chain_fits(e, B, len_override) && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
+}
 
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
 QkvAttnArgs make_qkv_attn_args(ma_engine* e, int l, const float* x_in, const float* ln_g, const float* ln_b, int len_override, Rows rw) {
@@ -510,7 +530,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     const float* resid = ln_g ? h0 : x_in;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     if (!(parts & 1)) {
-    } else if (fuse_qkv_attn(e)) {
+    } else if (fuse_qkv_attn(e, B, len_override)) {
         // q, k, v projection + split-KV attention in one launch (qkv_attn.hpp): the exchange between them stays inside a head
         QkvAttnArgs a = make_qkv_attn_args(e, l, x_in, ln_g, ln_b, len_override, rw);
         a.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
@@ -536,7 +556,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     }
     bool fc2_done = false;
     if (!(parts & 2)) return;
-    if (fuse_oproj_fc1(e)) {
+    if (fuse_oproj_fc1(e, B, len_override)) {
         // y1 = h + Wo a + bo; h1 = LN1(y1); f = relu(W1 h1 + b1) [; y2 = h1 + W2 f + b2] in one launch: y1 (and f) all-gathered inside it (oproj_fc1.hpp)
         const bool with_fc2 = e->opt_fuse_fc2 != 0;
         fc2_done = with_fc2;
@@ -571,7 +591,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     }
 }
 
-bool fuse_layer(ma_engine* e) { return e->opt_fuse_layer && fuse_qkv_attn(e) && fuse_oproj_fc1(e) && e->opt_fuse_fc2; }
+bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
 
 // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp); belongs to the "cache" class of the profiler
 void enqueue_layer_pair(ma_engine* e, hipStream_t s, int l, const float* resid, int len_override, StepTimer& tm, Rows rw) {
@@ -660,7 +680,7 @@ void check_chain_error(ma_engine* e, hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(s));
     if (*e->h_chain_err) {
         HIP_CHECK(hipMemsetAsync(e->d_chain_err, 0, sizeof(unsigned), s));
-        throw MaError(MA_ERR_HIP, "a fused decode launch's in-launch exchange timed out (not all blocks of the grid resident?)");
+        throw ChainTimeout("a fused decode launch's in-launch exchange timed out (not all blocks of the grid resident?)");
     }
 }
 
@@ -684,7 +704,7 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         enqueue_layers_mfma(e, s, de, len_override, tm, rw);
     } else {
         const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
-        if (fuse_layer(e) && c.layers >= 2) {
+        if (fuse_layer(e, rw.B, len_override) && c.layers >= 2) {
             // first half of layer 0 | (second half of l + first half of l + 1) x (L - 1) | second half of layer L - 1
             const float* h0 = e->d_h0 + (size_t)rw.r0 * H;
             enqueue_layer(e, s, 0, de, nullptr, nullptr, len_override, tm, rw, 1);
@@ -823,7 +843,7 @@ ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
 // generate() for a batch of B rows: every row is prefilled, then all rows step together (they share the weight stream and
 // the cache position) until every row has emitted eos or max_new_tokens ([3p] GenerationMixin: a finished row keeps
 // stepping and emits pad).  tokens_out (B, maxnew) device; lengths host (B).  Returns the number of valid columns.
-int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, const ma_sample_cfg& sc, long long* tokens_out, int32_t* lengths) {
+int generate_batch_once(ma_engine* e, hipStream_t s, const float* prefix, int B, const ma_sample_cfg& sc, long long* tokens_out, int32_t* lengths) {
     const int maxn = sc.max_new_tokens;
     const int total = B * e->maxnew;
     hipLaunchKernelGGL(fill_tokens_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, e->w_tokens, (long long)TOK_PAD, total);
@@ -843,7 +863,9 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
     int produced = 1;
     bool finished = false;
     while (produced < maxn && !finished) {
-        const int burst = std::min(sc.check_every, maxn - produced);
+        // the first burst is ONE step: a grid whose blocks are not all resident (device shared with another stream / process) shows
+        // in the error word after the first fused launch, not after 64 steps of zero-filled exchanges
+        const int burst = std::min(produced == 1 ? 1 : sc.check_every, maxn - produced);
         for (int i = 0; i < burst; ++i) launch_step(e, s, B, impl);
         produced += burst;
         HIP_CHECK(hipMemcpyAsync(e->h_state, e->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost, s));
@@ -865,6 +887,21 @@ int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, cons
     }
     if (tokens_out != e->w_tokens) HIP_CHECK(hipMemcpyAsync(tokens_out, e->w_tokens, (size_t)total * sizeof(long long), hipMemcpyDeviceToDevice, s));
     return nmax;
+}
+
+// A timed-out in-launch exchange is not an error of the request: the fused launches need the whole grid resident, which another
+// stream or process on the device can take away at any time.  The engine then stops using them (chain_resident = false: five
+// launches per layer, no spinning, bit-identical results -- tests/test_gpu_persist.py) and runs the generation again from the prefill.
+int generate_batch(ma_engine* e, hipStream_t s, const float* prefix, int B, const ma_sample_cfg& sc, long long* tokens_out, int32_t* lengths) {
+    try {
+        return generate_batch_once(e, s, prefix, B, sc, tokens_out, lengths);
+    } catch (const ChainTimeout&) {
+        if (!e->chain_resident) throw;
+        e->chain_resident = false;
+        e->chain_fallbacks++;
+        drop_graphs(e);
+    }
+    return generate_batch_once(e, s, prefix, B, sc, tokens_out, lengths);
 }
 
 // ------------------------------------------------------------------------------------------------ detokenizer
@@ -994,7 +1031,8 @@ void build_engine(ma_engine* e) {
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, layer_fused_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); occ_a = occ_b = occ_c = 0; }
             const int occ_min = std::min(std::min(occ_a, occ_b), occ_c);
             const int usable = occ_min > 1 ? occ_min - 1 : occ_min;              // blocks per CU counted on
-            e->chain_resident = (long)e->n_cus * usable * 4 >= 256L * 5;
+            e->resident_blocks = (long)e->n_cus * usable;
+            e->chain_resident = e->resident_blocks * 4 >= 256L * 5;
         }
         e->persist_shape = e->bf16 && c.hidden == PS_H && c.ffn == PS_F && c.heads == PS_HEADS && c.codebook_dim == PS_H && c.heads * ATTN_NCHUNK == PS_CUS &&
                            e->V >= PS_CUS * 32 && e->V <= PS_CUS * 33 && e->n_cus == PS_CUS && (size_t)prop.sharedMemPerBlockOptin >= PL_TOTAL;
@@ -1079,7 +1117,12 @@ int guarded(ma_engine* e, F f) {
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* ma_version(void) { return "meshanything_amd 0.1 (gfx950)"; }
+// MA_SRC_HASH: SHA-256 over the sources and flags this library was compiled from (meshanything_amd/build.py passes it); the loader
+// compares it with the tree next to the library, so a stale .so cannot travel to a GPU box unnoticed -- and needs no side file
+#ifndef MA_SRC_HASH
+#define MA_SRC_HASH "unknown"
+#endif
+const char* ma_version(void) { return "meshanything_amd 0.1 (gfx950) src=" MA_SRC_HASH; }
 
 const char* ma_last_error(const ma_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -1109,6 +1152,7 @@ void ma_engine_destroy(ma_engine* e) {
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->arena) (void)hipFree(e->arena);
+    if (e->stage) (void)hipFree(e->stage);
     if (e->kv) (void)hipFree(e->kv);
     if (e->h_state) (void)hipHostFree(e->h_state);
     if (e->h_err) (void)hipHostFree(e->h_err);
@@ -1146,6 +1190,10 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
             gemv_k8_ksplit() = (int)value; drop_graphs(e);
         } else if (n == "fuse_qkv_attn") { e->opt_fuse_qkv_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "fuse_oproj_fc1") { e->opt_fuse_oproj_fc1 = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "chain_resident") {            // 0: never spin on other blocks (five-launch chain); 1: re-arm after a fallback, if the device allows
+            e->chain_resident = value != 0 && e->resident_blocks * 4 >= 256L * 5;
+            drop_graphs(e);
+        }
         else if (n == "decode_impl") {
             if (value != 0 && value != 1) throw MaError(MA_ERR_INVALID, "decode_impl must be 0 (launch chain) or 1 (persistent step)");
             e->opt_decode_impl = (int)value;
@@ -1168,6 +1216,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "decode_impl") *value = e->opt_decode_impl;
         else if (n == "persist_available") *value = e->persist_shape ? 1 : 0;
         else if (n == "chain_resident") *value = e->chain_resident ? 1 : 0;
+        else if (n == "chain_fallbacks") *value = e->chain_fallbacks;
+        else if (n == "resident_blocks") *value = e->resident_blocks;
         else if (n == "use_graph") *value = e->cfg.use_graph;
         else if (n == "dense_rows") *value = e->dense_rows;
         else if (n == "mfma_min_batch") *value = e->opt_mfma_min_batch;
@@ -1187,10 +1237,43 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
     });
 }
 
+// Large tensors are uploaded in their STORED dtype and converted into their arena slot on the device (the host-side loop of
+// pack_tensor converts ~150 M elements per second on one core: 4.4 s for the 350M checkpoint, against 0.4 s this way; same f2bf
+// rounding, same bytes -- tests/test_gpu_model_api.py compares the two arenas).  Returns false when the tensor is not eligible:
+// pack_tensor then handles it, including every error message.
+static bool load_tensor_on_device(ma_engine* e, const ma_tensor_desc& t) {
+    if (!t.name || !t.data || t.ndim < 1 || t.ndim > 3 || t.dtype < MA_DTYPE_F32 || t.dtype > MA_DTYPE_F16) return false;
+    bool dropped;
+    const Source* s = find_source(e->L, t.name, &dropped);
+    if (!s || dropped) return false;
+    long long lead = 1;
+    for (int i = 0; i + 1 < t.ndim; ++i) lead *= t.shape[i];
+    if (lead != s->src_rows || t.shape[t.ndim - 1] != s->src_cols) return false;
+    const size_t elems = (size_t)s->take_rows * s->take_cols;
+    if (elems < (1u << 16)) return false;
+    const Entry& en = e->L.entries[s->entry];
+    const size_t src_esz = t.dtype == MA_DTYPE_F32 ? 4 : 2, src_bytes = (size_t)s->take_rows * s->src_cols * src_esz;
+    if (e->stage_bytes < src_bytes) {
+        if (e->stage) (void)hipFree(e->stage);
+        e->stage = nullptr; e->stage_bytes = 0;
+        HIP_CHECK(hipMalloc(&e->stage, src_bytes));
+        e->stage_bytes = src_bytes;
+    }
+    HIP_CHECK(hipMemcpy(e->stage, t.data, src_bytes, hipMemcpyHostToDevice));
+    const int esz = en.dtype == MA_DTYPE_F32 ? 4 : 2;
+    void* dst = e->arena + en.offset + s->dst_elem * esz;
+    const int blocks = (int)std::min<size_t>((elems + 255) / 256, 65535u * 16u);
+    hipLaunchKernelGGL(cvt_weight_kernel, dim3(blocks), dim3(256), 0, nullptr, e->stage, t.dtype, s->src_cols, dst, esz, en.cols, s->take_rows, s->take_cols);
+    HIP_CHECK(hipGetLastError());
+    e->ps.filled[s->entry] += elems;
+    return true;
+}
+
 int ma_engine_load_weights(ma_engine* e, const ma_tensor_desc* tensors, int n) {
     if (!e || (!tensors && n > 0)) return MA_ERR_INVALID;
     return guarded(e, [&] {
         for (int i = 0; i < n; ++i) {
+            if (load_tensor_on_device(e, tensors[i])) continue;
             std::string err;
             int rc = pack_tensor(e->L, e->ps, tensors[i], err, [&](size_t off, const void* p, size_t nb) {
                 HIP_CHECK(hipMemcpy(e->arena + off, p, nb, hipMemcpyHostToDevice));
@@ -1205,6 +1288,8 @@ int ma_engine_finalize_weights(ma_engine* e) {
     return guarded(e, [&] {
         std::string missing;
         if (!pack_complete(e->L, e->ps, missing)) throw MaError(MA_ERR_MISSING, "checkpoint incomplete, missing: " + missing);
+        HIP_CHECK(hipDeviceSynchronize());                   // the device-side conversions of the last tensors
+        if (e->stage) { (void)hipFree(e->stage); e->stage = nullptr; e->stage_bytes = 0; }
         e->weights_ready = true; e->embtab_ready = false;
     });
 }
@@ -1601,6 +1686,17 @@ int ma_op_rows_prologue(int pro, const float* x, int nparts, int B, const float*
     });
 }
 
+int ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, void* stream) {
+    return guarded(nullptr, [&] {
+        if (n_blocks < 1 || n_blocks > 4096 || lds_bytes < 64 || lds_bytes > 160 * 1024 || microseconds < 1 || microseconds > 2000000)
+            throw MaError(MA_ERR_INVALID, "ma_op_occupy_cus: bad arguments");
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(64), (size_t)lds_bytes, reinterpret_cast<hipStream_t>(stream), (unsigned long long)microseconds * 100ull,
+                           (unsigned*)nullptr);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 size_t ma_decode_attention_workspace_bytes(int H) {
     if (H < 1) return 0;
     return attn_workspace_floats(H) * sizeof(float);
@@ -1666,8 +1762,9 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
             out->ms[cls] = timed(cls, &n);
             out->launches[cls] = n;
         }
-        if (impl == 1) check_persist_error(e, s);
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (impl == 1) check_persist_error(e, s);
+        else check_chain_error(e, s);                       // timings of zero-filled exchanges are not timings
     });
 }
 
@@ -1697,6 +1794,7 @@ int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launch
             HIP_CHECK(hipStreamSynchronize(s));
             *n_launches = (int)k.size();
             for (size_t i = 0; i < k.size(); ++i) { kinds[i] = k[i]; blocks[i] = b[i]; }
+            check_chain_error(e, s);
         } catch (...) { (void)hipFree(d_tr); throw; }
         HIP_CHECK(hipFree(d_tr));
     });

@@ -211,4 +211,28 @@ __global__ void fill_tokens_kernel(long long* p, long long v, int n) {
     if (idx < n) p[idx] = v;
 }
 
+// checkpoint tensor (fp32 | bf16 | fp16 as stored, rows x src_ld) -> its arena slot (fp32 or bf16, leading dimension dst_ld): the device
+// half of ma_engine_load_weights.  Same rounding as the host packer (f2bf: round to nearest even).
+__global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, int src_ld, void* __restrict__ dst, int dst_esz, int dst_ld, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cols, k = i - r * cols, si = r * src_ld + k;
+        float v;
+        if (src_dtype == MA_DTYPE_F32) v = reinterpret_cast<const float*>(src)[si];
+        else if (src_dtype == MA_DTYPE_BF16) v = bf2f(reinterpret_cast<const uint16_t*>(src)[si]);
+        else v = (float)reinterpret_cast<const _Float16*>(src)[si];
+        if (dst_esz == 4) reinterpret_cast<float*>(dst)[r * dst_ld + k] = v;
+        else reinterpret_cast<bf16_t*>(dst)[r * dst_ld + k] = f2bf(v);
+    }
+}
+
+// test aid (ma_op_occupy_cus): a workgroup that holds its dynamic LDS allocation and sleeps until `ticks` of the 100 MHz counter passed
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ char occupy_lds[];
+    occupy_lds[threadIdx.x] = 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (occupy_lds[threadIdx.x] == 2 && sink) *sink = 1;       // never true: keeps the allocation alive
+}
+
 }  // namespace ma

@@ -21,7 +21,6 @@
 #include "attn_decode.hpp"
 #include "common.hpp"
 #include "gemv.hpp"
-#include "persist.hpp"
 #include "state.hpp"
 
 namespace ma {
@@ -155,7 +154,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             }
             if (!pend) break;
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+            if (xchg_expired(spins, t0, a.err)) {
                 if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int k = 0; k < NK; ++k) yr[k * 64 + lane] = 0.f;
@@ -239,7 +238,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 }
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                if (xchg_expired(spins, t0, a.err)) {
                     if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { fr[2 * (k * 64 + lane)] = 0.f; fr[2 * (k * 64 + lane) + 1] = 0.f; }
@@ -294,7 +293,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 }
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+                if (xchg_expired(spins, t0, a.err)) {
                     if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) yr[k * 64 + lane] = 0.f;

@@ -33,18 +33,8 @@
 
 namespace ma {
 
-typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-struct DecLayerPtrs {
-    const void *qkv_w, *o_w, *fc1_w, *fc2_w;
-    const float *qkv_b, *o_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-};
-
 constexpr int PS_CUS = 256, PS_H = 1024, PS_F = 4096, PS_HEADS = 16, PS_THREADS = 384;
 constexpr int PS_UNIT = 8192, PS_RING = 16, PS_UNITS_LAYER = 12, PS_UNITS_HEAD = 9;
-constexpr u64 PS_TIMEOUT_TICKS = 20ull * 100000ull;            // 20 ms of the 100 MHz counter
 
 // granule buffer (8-byte words)
 constexpr int PG_Y2 = 0, PG_Y1 = 1024, PG_QKV = 2048, PG_PART = 5120, PG_A = PG_PART + PS_HEADS * ATTN_NCHUNK * 66, PG_FFN = PG_A + 512,
@@ -95,9 +85,6 @@ __device__ __forceinline__ bool ps_wait(unsigned* ctrl, int idx, unsigned target
 __device__ __forceinline__ void ps_bump(unsigned* ctrl, int idx, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(ctrl + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void ps_publish(u64* gran, int idx, unsigned epoch, unsigned value) {
-    __hip_atomic_store((gu64*)gran + idx, ((u64)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void ps_glds16(const void* gsrc, unsigned lds_dst) {      // one 1 KiB LDS-DMA piece (MI355X guide 5.7)
     unsigned keep;

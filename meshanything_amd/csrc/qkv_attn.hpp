@@ -22,7 +22,6 @@
 #include "attn_decode.hpp"
 #include "common.hpp"
 #include "gemv.hpp"
-#include "persist.hpp"
 #include "state.hpp"
 
 namespace ma {
@@ -167,7 +166,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) {
+            if (xchg_expired(spins, t0, a.err)) {
                 if (lane == 0) __hip_atomic_fetch_or(a.err, QA_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 qg[lane] = 0.f; kvg[lane] = 0; kvg[64 + lane] = 0;
                 break;

@@ -20,4 +20,10 @@ struct DecState {
     int max_new;
 };
 
+// weights of one OPT decoder layer inside the arena ([3p] OPTDecoderLayer; q/k/v fused into one [3H][H] matrix at load)
+struct DecLayerPtrs {
+    const void *qkv_w, *o_w, *fc1_w, *fc2_w;
+    const float *qkv_b, *o_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
 }  // namespace ma

@@ -194,6 +194,8 @@ class Engine:
         if n > cfg.max_new_tokens:
             raise ValueError(f"{n} generated tokens per row, but 9*n_max_faces+2 = {cfg.max_new_tokens} is the most generate() can return")
         t = results.to(self.device, torch.int64)
+        if n == 0:                                                   # nothing generated: every slot is the eos padding of meshanything.py:141-142
+            t = torch.zeros(B, 1, dtype=torch.int64, device=self.device)     # (an empty tensor has no data pointer to hand over)
         if n > 0 and t.stride(1) != 1:
             t = t.contiguous()
         ld = t.stride(0) if (B > 1 and n > 0) else max(n, 1)        # rows are read in place (a [:, :n] view of generate()'s buffer)
@@ -264,6 +266,12 @@ class Engine:
         self._check(self.lib.ma_persist_trace(self.h, kv_len, C.c_void_p(out.ctypes.data), C.byref(n), _stream_ptr()))
         self.last_compute_trace = out[256 * 320:].reshape(256, 512)
         return out[:256 * 320].reshape(256, 320)[:, :n.value]
+
+    def occupy_cus(self, n_blocks: int, microseconds: int, stream: Optional[torch.cuda.Stream] = None, lds_bytes: int = 160 * 1024) -> None:
+        """Test aid (ma_op_occupy_cus): park `n_blocks` workgroups holding `lds_bytes` of LDS each (default: a whole CU) on `stream` for
+        `microseconds`, so that a test can take CUs away from the engine's own stream."""
+        sp = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+        self._check(self.lib.ma_op_occupy_cus(int(n_blocks), int(lds_bytes), int(microseconds), sp))
 
     # ---------------------------------------------------------------- measurement
     def profile_decode(self, kv_len: int, steps: int = 4) -> Dict[str, object]:

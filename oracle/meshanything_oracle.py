@@ -1,4 +1,4 @@
-"""CPU oracle for the MeshAnything hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+"""Oracle for the MeshAnything hot path (plain PyTorch, CPU by default) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this
 module.  The product (`meshanything_amd/`) never does; it fails loudly without its HIP library.
@@ -28,6 +28,13 @@ and against the container's transformers copy: `OPTLearnedPositionalEmbedding`, 
 it here: flash-attn + hub downloads): the `generate()` loop as a whole -- it is restated
 (`generate`) from those pinned pieces.
 
+Device (`device`): "cpu" (default; what the CPU suite, the golden pins and bench.py's cpu_baseline use) or a torch-ROCm device.
+  On "cuda" the SAME statements below run as stock PyTorch fp32 ops (rocBLAS GEMMs with TF32-style shortcuts disabled, eager
+  softmax / LayerNorm): still an implementation independent of the HIP engine, but the long verifications of the GPU suite
+  (teacher-forced passes over thousands of tokens at the 350M shape) no longer depend on the GPU box's host cores -- the
+  driver's un-tasksetted run of round 2 spent its whole 1200 s there.  Public methods take tensors from any device and return
+  CPU tensors; tests/test_gpu_oracle_device.py cross-checks the two devices against each other.
+
 Precision policy (`policy`):
   "fp32": no rounding anywhere -- the reference's CPU-equivalent arithmetic.
   "bf16": mirrors the engine's MA_DTYPE_BF16 mode so that comparisons are like-for-like:
@@ -37,6 +44,7 @@ Precision policy (`policy`):
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -83,14 +91,68 @@ def sample_points(cur_data: np.ndarray, n: int = 4096) -> np.ndarray:
     return cur_data[idx]
 
 
+def _move(x, device):
+    """Tensors (also inside tuples / lists / dicts) -> device; everything else untouched."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if isinstance(x, tuple):
+        return tuple(_move(v, device) for v in x)
+    if isinstance(x, list):
+        return [_move(v, device) for v in x]
+    if isinstance(x, dict):
+        return {k: _move(v, device) for k, v in x.items()}
+    return x
+
+
+def _api(fn):
+    """Public entry point of the oracle: tensor arguments go to the oracle's device, the OUTERMOST call hands its results back
+    on the CPU (calls between oracle methods stay on the device)."""
+    @functools.wraps(fn)
+    def wrap(self, *args, **kw):
+        if self.device.type == "cpu":
+            return fn(self, *args, **kw)
+        if self._depth == 0:            # containers (a KV-cache list updated in place) keep their identity
+            args = [a.to(self.device) if isinstance(a, torch.Tensor) else a for a in args]
+            kw = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        self._depth += 1
+        try:
+            r = fn(self, *args, **kw)
+        finally:
+            self._depth -= 1
+        return _move(r, "cpu") if (self._depth == 0 and self._keep == 0) else r
+    return wrap
+
+
 class Oracle:
-    def __init__(self, cfg: MAConfig, state_dict: Dict[str, np.ndarray], policy: str = "fp32"):
+    def __init__(self, cfg: MAConfig, state_dict: Dict[str, np.ndarray], policy: str = "fp32", device: str = "cpu"):
         assert policy in ("fp32", "bf16")
         self.cfg = cfg
         self.policy = policy
-        self.sd: Dict[str, torch.Tensor] = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in state_dict.items()}
+        self.device = torch.device(device)
+        self._depth = 0                           # nesting of public calls (arguments are moved by the outermost one only)
+        self._keep = 0                            # > 0 inside `with oracle.on_device()`: results stay on the oracle's device
+        if self.device.type == "cuda":            # plain fp32 arithmetic in the library GEMMs the torch ops reach
+            torch.backends.cuda.matmul.allow_tf32 = False
+            torch.backends.cudnn.allow_tf32 = False
+            torch.set_float32_matmul_precision("highest")
+        self.sd: Dict[str, torch.Tensor] = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)).to(self.device)
+                                            for k, v in state_dict.items()}
         self._wcache: Dict[str, torch.Tensor] = {}
         self._accept_bert_fused()
+
+    def on_device(self):
+        """Context manager: oracle methods called inside keep their results on the oracle's device (the verifiers below reduce
+        thousands of logit rows there instead of on the host)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._keep += 1
+            try:
+                yield self
+            finally:
+                self._keep -= 1
+        return cm()
 
     # ------------------------------------------------------------------ primitives
     def _accept_bert_fused(self) -> None:
@@ -150,13 +212,13 @@ class Oracle:
         Sk = k.shape[1]
         kt = k.permute(0, 2, 3, 1)          # B,H,D,Sk
         vt = v.permute(0, 2, 1, 3)          # B,H,Sk,D
-        out = torch.empty(B, Sq, H * D)
+        out = torch.empty(B, Sq, H * D, device=q.device)
         for s in range(0, Sq, q_chunk):
             e = min(Sq, s + q_chunk)
             w = (q[:, s:e].permute(0, 2, 1, 3) @ kt) * scale       # B,H,c,Sk
             if causal_offset is not None:
-                qi = torch.arange(s, e)[:, None] + causal_offset
-                kj = torch.arange(Sk)[None, :]
+                qi = torch.arange(s, e, device=q.device)[:, None] + causal_offset
+                kj = torch.arange(Sk, device=q.device)[None, :]
                 w = w.masked_fill(kj > qi, float("-inf"))
             if self.policy == "bf16" and dense:
                 w = w.float()
@@ -168,10 +230,11 @@ class Oracle:
         return out
 
     # ------------------------------------------------------------------ point encoder (miche)
+    @_api
     def fourier_embed(self, pc: torch.Tensor) -> torch.Tensor:
         """FourierEmbedder.forward, embedder.py:87-105 with logspace freqs 2^0..2^(F-1), include_pi=False,
         include_input=True: cat(x, sin(x (x) f), cos(x (x) f)); (dim, freq) row-major inside sin/cos."""
-        freqs = 2.0 ** torch.arange(self.cfg.num_freqs, dtype=torch.float32)
+        freqs = 2.0 ** torch.arange(self.cfg.num_freqs, dtype=torch.float32, device=pc.device)
         embed = (pc[..., None].contiguous() * freqs).view(*pc.shape[:-1], -1)
         return torch.cat((pc, embed.sin(), embed.cos()), dim=-1)
 
@@ -189,6 +252,7 @@ class Oracle:
         x = x + self.linear(F.gelu(h), p + "mlp.c_proj.weight", p + "mlp.c_proj.bias")   # nn.GELU() = erf form
         return x
 
+    @_api
     def encode_latents(self, pc_normal: torch.Tensor) -> torch.Tensor:
         """AlignedShapeAsLatentPLModule.encode_latents (asl_pl_module.py:145-157) ->
         AlignedShapeLatentPerceiver.encode_latents (sal_perceiver.py:372-381) ->
@@ -216,6 +280,7 @@ class Oracle:
         assert lat.shape[1] == cfg.cond_length
         return lat      # cat([shape_embed[:,None], latents]) is the identity re-assembly of x[:,0], x[:,1:]
 
+    @_api
     def to_shape_latents(self, latents: torch.Tensor) -> torch.Tensor:
         """asl_pl_module.py:182-185: encode_kl_embed(sample_posterior=False) (sal_perceiver.py:383-396;
         DiagonalGaussianDistribution.mode = first half of pre_kl's output, distributions.py:34,69-70),
@@ -227,6 +292,7 @@ class Oracle:
             x = self._miche_attn_block(x, SM + f"transformer.resblocks.{n}.")
         return x
 
+    @_api
     def process_point_feature(self, point_feature: torch.Tensor) -> torch.Tensor:
         """MeshAnything.process_point_feature, meshanything.py:125-132 -> (B,T,hidden) decoder prefix."""
         head = self.linear(point_feature[:, 0], "cond_head_proj.weight", "cond_head_proj.bias")
@@ -235,6 +301,7 @@ class Oracle:
         return torch.cat([head[:, None], rest], dim=1)
 
     # ------------------------------------------------------------------ autoregressive decoder (ShapeOPT)
+    @_api
     def embed_tokens(self, ids: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         """Input embedding of decode step(s): ids (n,) = token fed at step t (n,) (t >= 1 = number of tokens
         generated so far).  shape_opt.py:237-245 (embed_with_vae), 448-460 (OPTFacePositionalEmbedding:
@@ -242,7 +309,7 @@ class Oracle:
         359/364 + OPTLearnedPositionalEmbedding (row = (cond_length + t - 1) + 2)."""
         cfg = self.cfg
         special = ids < 3
-        e = torch.zeros(ids.shape[0], cfg.hidden)
+        e = torch.zeros(ids.shape[0], cfg.hidden, device=self.device)
         if special.any():
             e[special] = self.sd[DEC + "extra_embeds.weight"][ids[special]]
         if (~special).any():
@@ -254,11 +321,13 @@ class Oracle:
         e = e + self.sd[DEC + "embed_positions.weight"][cfg.cond_length + t - 1 + 2]
         return e
 
+    @_api
     def embed_prefix(self, prefix: torch.Tensor) -> torch.Tensor:
         """shape_opt.py:331-337 (cond_embed[0]) + embed_positions rows 2..T+1 (prefill)."""
         T = prefix.shape[1]
         return prefix + self.sd[DEC + "cond_embed.weight"][0] + self.sd[DEC + "embed_positions.weight"][2:2 + T]
 
+    @_api
     def opt_layers(self, h: torch.Tensor, cache: Optional[List[Tuple[torch.Tensor, torch.Tensor]]]) -> torch.Tensor:
         """24x post-LN OPTDecoderLayer ([3p] transformers 4.39.3; container copy modeling_opt.py:202-253):
         a = softmax(q k^T / 8) v (causal); h = LN(h + Wo a + bo); h = LN(h + W2 relu(W1 h + b1) + b2); eps 1e-5.
@@ -286,6 +355,7 @@ class Oracle:
             h = self.ln(h + self.linear(f, p + "fc2.weight", p + "fc2.bias"), p + "final_layer_norm.", 1e-5)
         return h
 
+    @_api
     def lm_head(self, h: torch.Tensor) -> torch.Tensor:
         return self.linear(h, "transformer.lm_head.weight")          # shape_opt.py:24,155 (no bias, un-tied)
 
@@ -296,6 +366,7 @@ class Oracle:
         Returns (kept token ids, their final probabilities) ordered by descending logit, ties by ascending id.
         top-k keeps every score >= the k-th largest; top-p sorts ascending, removes the prefix whose cumulative
         softmax mass is <= 1 - top_p, always keeps the largest."""
+        logits = logits.detach().cpu()                             # scalar walks below: never element-wise off a device
         V = logits.shape[0]
         k = min(top_k, V)
         order = sorted(range(V), key=lambda i: (-float(logits[i]), i))
@@ -335,6 +406,7 @@ class Oracle:
         kept, probs = self.topk_topp_filter(logits)
         return self.sample_from(kept, probs, float(u))
 
+    @_api
     def generate(self, prefix: torch.Tensor, max_new_tokens: Optional[int] = None, sampling: bool = False,
                  uniforms: Optional[np.ndarray] = None, suppress_eos: bool = False,
                  return_logits: bool = False):
@@ -344,7 +416,7 @@ class Oracle:
         cfg = self.cfg
         B = prefix.shape[0]
         maxn = cfg.max_new_tokens if max_new_tokens is None else max_new_tokens
-        out = torch.full((B, maxn), PAD, dtype=torch.long)
+        out = torch.full((B, maxn), PAD, dtype=torch.long, device=self.device)
         all_logits = []
         n_done = 0
         for b in range(B):                      # rows are independent; run them one by one
@@ -356,7 +428,7 @@ class Oracle:
             out[b, 0] = tok
             n = 1
             while n < maxn and tok != EOS:
-                e = self.embed_tokens(torch.tensor([tok]), torch.tensor([n]))
+                e = self.embed_tokens(torch.tensor([tok], device=self.device), torch.tensor([n], device=self.device))
                 h = self.opt_layers(e[None], cache)
                 logits = self.lm_head(h[0, -1])
                 if return_logits:
@@ -369,6 +441,7 @@ class Oracle:
         out = out[:, :n_done]
         return (out, all_logits) if return_logits else out
 
+    @_api
     def teacher_forced_logits(self, prefix: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
         """Logits the decoder assigns at every step when fed `tokens` (n,) as its own past output, computed as
         ONE causal pass (prefix + embedded tokens[:-1]) instead of n cached steps.  Row j = distribution of
@@ -377,19 +450,20 @@ class Oracle:
         n = tokens.shape[0]
         h0 = self.embed_prefix(prefix)
         if n > 1:
-            e = self.embed_tokens(tokens[:-1], torch.arange(1, n))
+            e = self.embed_tokens(tokens[:-1], torch.arange(1, n, device=self.device))
             h0 = torch.cat([h0, e[None]], dim=1)
         h = self.opt_layers(h0, None)
         return self.lm_head(h[0, self.cfg.cond_length - 1:])
 
     # ------------------------------------------------------------------ post-processing + detokenizer
+    @_api
     def postprocess_tokens(self, results: torch.Tensor) -> torch.Tensor:
         """meshanything.py:141-142,163-172: pad to generate_length with eos, drop first and last slot,
         {bos,eos,pad} -> -1, others -= 3.  (B, <=max_new) -> (B, n_max_faces*9) in [-1, codebook_size)."""
         B = results.shape[0]
         L = self.cfg.max_new_tokens
         assert results.shape[1] <= L
-        outputs = torch.ones(B, L, dtype=torch.long) * EOS
+        outputs = torch.ones(B, L, dtype=torch.long, device=results.device) * EOS
         outputs[:, :results.shape[1]] = results
         outputs = outputs[:, 1:-1].clone()
         outputs[outputs == BOS] = PAD_ID
@@ -398,6 +472,7 @@ class Oracle:
         outputs[outputs != PAD_ID] -= 3
         return outputs
 
+    @_api
     def get_codes(self, indices: torch.Tensor) -> torch.Tensor:
         """MeshAnything.get_codes, meshanything.py:178-212: per vertex, sum of the 3 (shared-codebook) rows;
         pad (-1) entries contribute zero.  (B, nf*9) -> (B, nf*3, codebook_dim)."""
@@ -424,6 +499,7 @@ class Oracle:
         x = self.ln(x + self.linear(f, p + "output.dense.weight", p + "output.dense.bias"), p + "output.LayerNorm.", 1e-12)
         return x
 
+    @_api
     def detok_point_feature(self, encode_feature: torch.Tensor) -> torch.Tensor:
         """NoiseResistantDecoder.process_point_feature, meshanything.py:42-48."""
         head = self.linear(encode_feature[:, 0], TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias")
@@ -431,6 +507,7 @@ class Oracle:
         pf = torch.cat([head[:, None], rest], dim=1)
         return self.ln(pf + self.sd[TOK + "point_pe.weight"][None, :pf.shape[1]], TOK + "point_layernorm.", 1e-5)
 
+    @_api
     def detokenize(self, input_ids: torch.Tensor, input_embeds: torch.Tensor, point_feature: torch.Tensor,
                    return_logits: bool = False):
         """NoiseResistantDecoder.forward, meshanything.py:50-80.  ids (B,nf*9) in [-1,C), embeds (B,nf*3,D),
@@ -458,6 +535,7 @@ class Oracle:
         return (cont, logits) if return_logits else cont
 
     # ------------------------------------------------------------------ facade
+    @_api
     def forward(self, pc_normal: torch.Tensor, sampling: bool = False, uniforms: Optional[np.ndarray] = None,
                 max_new_tokens: Optional[int] = None, suppress_eos: bool = False) -> Dict[str, torch.Tensor]:
         """MeshAnything.forward, meshanything.py:134-176."""
@@ -478,7 +556,9 @@ def verify_greedy_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Ten
     stream's token.  A disagreement whose oracle logit margin (top1 - logit[stream token]) is <= tol is an
     *ambiguous step* (the two implementations differ by summation order / a bf16 rounding flip and the step
     was a near-tie); a larger margin is a hard mismatch.  Returns counts and the worst margin."""
-    logits = oracle.teacher_forced_logits(prefix, tokens)
+    with oracle.on_device():
+        logits = oracle.teacher_forced_logits(prefix, tokens)
+    tokens = tokens.to(logits.device)
     if suppress_eos:
         logits = logits.clone()
         logits[:, EOS] = float("-inf")
@@ -498,7 +578,8 @@ def verify_sampled_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Te
     """Teacher-forced check of a top-k/top-p sampled stream drawn with injected uniforms: at every step the
     oracle's own filtered distribution must put `tokens[j]` on the CDF interval that contains uniforms[j]
     (within `tol`: two implementations differ by fp32 summation order in the logits)."""
-    logits = oracle.teacher_forced_logits(prefix, tokens)
+    logits = oracle.teacher_forced_logits(prefix, tokens).cpu()
+    tokens = tokens.cpu()
     n = tokens.shape[0]
     exact, ambiguous, hard = 0, 0, []
     for j in range(n):

@@ -315,6 +315,192 @@ def golden_shapeopt_forward(out, cfg: MAConfig, sd):
     print("ShapeOPTDecoder.forward: hidden absmax", float(torch.stack(hs).abs().max()), "cache length", int(pkv[0][0].shape[2]))
 
 
+def build_ref_decoder(cfg: MAConfig, sd):
+    """The reference's own ShapeOPTDecoder (shape_opt.py:181-438) carrying the checkpoint, its layers = the container's real
+    OPTDecoderLayer behind the 4.39.3-signature adapter (as in golden_shapeopt_forward); returns (decoder, lm_head weight)."""
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+    from MeshAnything.models.shape_opt import ShapeOPTConfig, ShapeOPTDecoder
+    c = ShapeOPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                       num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                       do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu",
+                       bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    c.quantize_codebook_dim = cfg.codebook_dim
+    c.face_per_token = 9
+    c.cond_length = cfg.cond_length
+    c._attn_implementation = "eager"
+    dec = ShapeOPTDecoder(c).eval()
+    dec._use_flash_attention_2 = True
+    for nm in ("extra_embeds.weight", "input_layer.weight", "input_layer.bias", "embed_positions.weight",
+               "token_embed_positions.weight", "cond_embed.weight"):
+        obj = dec
+        parts = nm.split(".")
+        for p_ in parts[:-1]:
+            obj = getattr(obj, p_)
+        getattr(obj, parts[-1]).data.copy_(torch.from_numpy(sd[DEC + nm]))
+    dec.quantize_codebooks = torch.nn.Parameter(torch.from_numpy(sd[DEC + "quantize_codebooks"]))
+    oc = OPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                   num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                   do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu")
+    oc._attn_implementation = "eager"
+    layers = []
+    for i in range(cfg.layers):
+        L = OPTDecoderLayer(oc, layer_idx=i).eval()
+        sub = {k[len(DEC + f"layers.{i}."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(DEC + f"layers.{i}.")}
+        L.load_state_dict(sub, strict=True)
+        layers.append(_Layer439(L))
+    dec.layers = torch.nn.ModuleList(layers)
+    return dec, torch.from_numpy(sd["transformer.lm_head.weight"])
+
+
+def golden_anchor(out, cfg: MAConfig, sd, lat: torch.Tensor, prefix: torch.Tensor, steps: int = 64):
+    """Engine-independent anchor at the 350M shape: the REFERENCE modules' own fp32 numbers for
+    (a) a `steps`-step greedy decode of pc_examples/mouse.npy through ShapeOPTDecoder.forward (shape_opt.py:248-438) driven like
+        generate() drives it -- per step the chosen token, the top-16 logits, the top-1/top-2 margin and the logits of every 64th
+        vocabulary column (eos suppressed, as the throughput configs run);
+    (b) the detokenizer's coordinate logits (NoiseResistantDecoder.forward, meshanything.py:50-80; recorded by a forward hook on
+        `to_coor_logits`, the reference code path itself is untouched): argmax bin and top-1/top-2 margin of all 800 x 9 coordinates.
+    The GPU tests hold the bf16 engine's logits (ma_engine_read_logits) and bins against THESE numbers, not against the oracle."""
+    from MeshAnything.models.meshanything import NoiseResistantDecoder, MeshAnything as RefMeshAnything
+    dec, lm_head = build_ref_decoder(cfg, sd)
+    B, T = 1, cfg.cond_length
+    cols = np.arange(0, cfg.vocab, 64)
+    toks, top_i, top_v, margin, lcols = [], [], [], [], []
+
+    def record(h):
+        lg = (h @ lm_head.T)[0].clone()
+        lg[1] = float("-inf")                                  # suppress_eos
+        tv, ti = torch.topk(lg, 16)
+        toks.append(int(ti[0])); top_i.append(ti.numpy()); top_v.append(tv.numpy()); margin.append(float(tv[0] - tv[1]))
+        lcols.append(lg[cols].numpy())
+        return int(ti[0])
+    with torch.no_grad():
+        o = dec(inputs_embeds=prefix, attention_mask=torch.ones(B, T, dtype=torch.long), use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        tok = record(o.last_hidden_state[:, -1])
+        for t in range(1, steps + 1):
+            o = dec(input_ids=torch.tensor([[tok]]), past_key_values=pkv, attention_mask=torch.ones(B, T + t, dtype=torch.long),
+                    use_cache=True, return_dict=True)
+            pkv = o.past_key_values
+            tok = record(o.last_hidden_state[:, -1])
+    out["anchor_tokens"] = np.array(toks, dtype=np.int64)          # steps + 1 tokens: from the prefill, then one per step
+    out["anchor_top_idx"] = np.stack(top_i).astype(np.int32)
+    out["anchor_top_val"] = np.stack(top_v).astype(np.float32)
+    out["anchor_margin"] = np.array(margin, dtype=np.float32)
+    out["anchor_cols"] = cols.astype(np.int32)
+    out["anchor_logits_cols"] = np.stack(lcols).astype(np.float32)
+    print(f"anchor decode: {steps + 1} tokens, margin min {min(margin):.4f} median {float(np.median(margin)):.4f}")
+    # (b) detokenizer logits of the golden ids (full.npz full_detok_ids), through the reference's own forward
+    args = types.SimpleNamespace(codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim)
+    tok_m = NoiseResistantDecoder(args)
+    sub = {k[len(TOK):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(TOK)}
+    tok_m.load_state_dict(sub, strict=True)
+    tok_m.eval()
+    ids = torch.from_numpy(np.load(os.path.join(HERE, "full.npz"))["full_detok_ids"])
+    ns = types.SimpleNamespace(num_quantizers=3)
+    ns.transformer = types.SimpleNamespace(model=types.SimpleNamespace(decoder=types.SimpleNamespace(
+        quantize_codebooks=torch.from_numpy(sd[DEC + "quantize_codebooks"]))))
+    seen = {}
+    hook = tok_m.to_coor_logits.register_forward_hook(lambda mod, inp, res: seen.__setitem__("logits", res.detach().clone()))
+    with torch.no_grad():
+        codes = RefMeshAnything.get_codes(ns, ids)
+        coords = tok_m(ids, codes, point_feature=lat)
+    hook.remove()
+    lg = seen["logits"][0]                                         # (nf, 9, 128)
+    tv, ti = torch.topk(lg, 2, dim=-1)
+    out["anchor_detok_bins"] = ti[..., 0].numpy().astype(np.int16)
+    out["anchor_detok_margin"] = (tv[..., 0] - tv[..., 1]).numpy().astype(np.float32)
+    out["anchor_detok_valid"] = (~torch.isnan(coords[0, :, 0, 0])).numpy()
+    assert np.array_equal(np.nan_to_num(coords.numpy(), nan=9.0), np.nan_to_num(np.load(os.path.join(HERE, "full.npz"))["full_detok_coords"], nan=9.0))
+    m = out["anchor_detok_margin"][out["anchor_detok_valid"]]
+    print(f"anchor detok: {int(out['anchor_detok_valid'].sum())} valid faces, margin quantiles 1% {np.quantile(m, 0.01):.4f} 10% {np.quantile(m, 0.1):.4f} 50% {np.quantile(m, 0.5):.4f}")
+
+
+def golden_shapeopt_generate(out, cfg: MAConfig, sd):
+    """THE OUTERMOST COMPOSITION: the reference's own `ShapeOPT` CausalLM wrapper
+    (shape_opt.py:18-178) -> ShapeOPTModel -> ShapeOPTDecoder.forward, driven by the container's `GenerationMixin.generate` with the
+    arguments of meshanything.py:143-151 (inputs_embeds, max_new_tokens, num_beams=1, bos/eos/pad ids).  Three shims bridge
+    transformers 4.39.3 -> 5.x, none touches the model's arithmetic or the loop's decisions:
+      1. `ShapeOPT.tie_weights` is called with keyword arguments by 5.x's post_init; the reference's override takes none -> the
+         keywords are dropped;
+      2. 5.x would hand the model a `DynamicCache`; the reference indexes a tuple cache (`past_key_values[0][0].shape[2]`,
+         shape_opt.py:342) -> the model declares no Cache-class support, so generate() passes None first and then whatever the
+         model returned, as 4.39.3 did;
+      3. 4.39.3's `OPTForCausalLM.prepare_inputs_for_generation` (inputs_embeds on the first call only, then the last token; the
+         method the reference inherited) is restated, because 5.x's generic one slices by `cache_position`.
+    The decoder layers are the container's real OPTDecoderLayer behind the 4.39.3 call signature (`_Layer439`), attention eager."""
+    import re
+    from MeshAnything.models.shape_opt import ShapeOPT, ShapeOPTConfig
+    from transformers import OPTConfig
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+    c = ShapeOPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                       num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                       do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu",
+                       bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    c.quantize_codebook_dim = cfg.codebook_dim
+    c.face_per_token = 9
+    c.cond_length = cfg.cond_length
+    c._attn_implementation = "eager"
+    orig_tie = ShapeOPT.tie_weights
+    ShapeOPT.tie_weights = lambda self, *a, **k: orig_tie(self)                                   # shim 1
+    ShapeOPT._supports_default_dynamic_cache = classmethod(lambda cls: False)                     # shim 2
+
+    def prepare(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):   # shim 3 ([3p] 4.39.3 modeling_opt.py)
+        if past_key_values is not None:
+            past_length = past_key_values[0][0].shape[2]
+            remove = past_length if input_ids.shape[1] > past_length else input_ids.shape[1] - 1
+            input_ids = input_ids[:, remove:]
+        mi = {"inputs_embeds": inputs_embeds} if (inputs_embeds is not None and past_key_values is None) else {"input_ids": input_ids}
+        mi.update({"past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"), "attention_mask": attention_mask})
+        return mi
+    ShapeOPT.prepare_inputs_for_generation = prepare
+
+    def build(sd_):
+        m = ShapeOPT(c).eval()
+        dec = m.model.decoder
+        dec._use_flash_attention_2 = True
+        oc = OPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers, ffn_dim=cfg.ffn,
+                       num_attention_heads=cfg.heads, max_position_embeddings=cfg.max_positions,
+                       do_layer_norm_before=False, word_embed_proj_dim=cfg.hidden, activation_function="relu")
+        oc._attn_implementation = "eager"
+        dec.layers = torch.nn.ModuleList([_Layer439(OPTDecoderLayer(oc, layer_idx=i).eval()) for i in range(cfg.layers)])
+        dec.quantize_codebooks = torch.nn.Parameter(torch.zeros(1, cfg.codebook_size, cfg.codebook_dim))      # meshanything.py:118
+        # the checkpoint's `transformer.*` keys, loaded strictly (main.py:104); the adapter nests each real layer under `.layer`
+        sub = {re.sub(r"(model\.decoder\.layers\.\d+)\.", r"\1.layer.", k[len("transformer."):]): torch.from_numpy(v) for k, v in sd_.items() if k.startswith("transformer.")}
+        res = m.load_state_dict(sub, strict=True)
+        return m
+    g = torch.Generator().manual_seed(6)
+    B = 4
+    prefix = torch.randn(B, cfg.cond_length, cfg.hidden, generator=g) * 0.7
+    m = build(sd)
+    with torch.no_grad():
+        base = m.generate(inputs_embeds=prefix, max_new_tokens=cfg.max_new_tokens, num_beams=1, bos_token_id=0, eos_token_id=1, pad_token_id=2)
+        short = m.generate(inputs_embeds=prefix, max_new_tokens=11, num_beams=1, bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    out["gen_prefix"] = prefix.numpy()
+    out["gen_tokens"] = base.numpy()
+    out["gen_tokens_max11"] = short.numpy()
+    # eos firing naturally at different steps per row: swap the lm_head rows of eos and of a token the rows emit at different positions
+    pick = None
+    for tok in sorted(set(base.flatten().tolist()) - {0, 1, 2}):
+        first = [(base[b] == tok).nonzero()[0].item() if (base[b] == tok).any() else None for b in range(B)]
+        if len(set(first)) >= 3:
+            pick = tok
+            break
+    assert pick is not None, "no token found that finishes the rows at different steps"
+    sd2 = dict(sd)
+    w = sd["transformer.lm_head.weight"].copy()
+    w[[1, pick]] = w[[pick, 1]]
+    sd2["transformer.lm_head.weight"] = w
+    m2 = build(sd2)
+    with torch.no_grad():
+        eos = m2.generate(inputs_embeds=prefix, max_new_tokens=cfg.max_new_tokens, num_beams=1, bos_token_id=0, eos_token_id=1, pad_token_id=2)
+    out["gen_eos_swap_token"] = np.array([pick])
+    out["gen_tokens_eos"] = eos.numpy()
+    ShapeOPT.tie_weights = orig_tie
+    print(f"ShapeOPT under GenerationMixin.generate: {tuple(base.shape)} tokens; eos variant (rows 1 <-> {pick} of lm_head) {tuple(eos.shape)}, "
+          f"row lengths {[int((eos[b] == 1).nonzero()[0]) + 1 if (eos[b] == 1).any() else eos.shape[1] for b in range(B)]}")
+
+
 def golden_detok(out, cfg: MAConfig, sd, tag: str, lat: torch.Tensor, seed: int):
     from MeshAnything.models.meshanything import NoiseResistantDecoder, MeshAnything as RefMeshAnything, undiscretize
     import transformers
@@ -395,6 +581,24 @@ def main():
         np.savez_compressed(os.path.join(HERE, "shapeopt_forward.npz"), **g)
         print("shapeopt_forward.npz", os.path.getsize(os.path.join(HERE, "shapeopt_forward.npz")) // 1024, "KiB")
         return
+    if "--only-generate" in sys.argv:                     # the outermost pin: ShapeOPT under GenerationMixin.generate (tiny shape)
+        tiny = MAConfig.tiny()
+        g = {}
+        golden_shapeopt_generate(g, tiny, synthetic_state_dict(tiny, include_unused=True))
+        np.savez_compressed(os.path.join(HERE, "shapeopt_generate.npz"), **g)
+        print("shapeopt_generate.npz", os.path.getsize(os.path.join(HERE, "shapeopt_generate.npz")) // 1024, "KiB")
+        return
+    if "--only-anchor" in sys.argv:                       # 350M-shape reference numbers for the bf16 engine's logits / bins
+        full = MAConfig.full()
+        sd_f = synthetic_state_dict(full, include_unused=True)
+        mouse = np.load(os.path.join(HERE, "dataset.npz"))["mouse_norm"]
+        scratch = {}
+        lat_f, prefix_f = golden_encoder(scratch, full, sd_f, "full", mouse, rows=[0])
+        g = {}
+        golden_anchor(g, full, sd_f, lat_f, prefix_f)
+        np.savez_compressed(os.path.join(HERE, "full_anchor.npz"), **g)
+        print("full_anchor.npz", os.path.getsize(os.path.join(HERE, "full_anchor.npz")) // 1024, "KiB")
+        return
     g = {}
     golden_dataset(g)
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **g)
@@ -419,11 +623,17 @@ def main():
     sd_f = synthetic_state_dict(full, include_unused=True)
     g = {}
     mouse = np.load(os.path.join(HERE, "dataset.npz"))["mouse_norm"]
-    lat_f, _ = golden_encoder(g, full, sd_f, "full", mouse, rows=[0, 1, 2, 3, 100, 255, 256])
+    lat_f, prefix_f = golden_encoder(g, full, sd_f, "full", mouse, rows=[0, 1, 2, 3, 100, 255, 256])
     del g["full_input"]                      # = dataset.npz mouse_norm
     golden_detok(g, full, sd_f, "full", lat_f, seed=22)
     np.savez_compressed(os.path.join(HERE, "full.npz"), **g)
-    for f in ("dataset.npz", "tiny.npz", "full.npz"):
+    g = {}
+    golden_shapeopt_generate(g, tiny, sd_t)
+    np.savez_compressed(os.path.join(HERE, "shapeopt_generate.npz"), **g)
+    g = {}
+    golden_anchor(g, full, sd_f, lat_f, prefix_f)
+    np.savez_compressed(os.path.join(HERE, "full_anchor.npz"), **g)
+    for f in ("dataset.npz", "tiny.npz", "full.npz", "shapeopt_generate.npz", "full_anchor.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

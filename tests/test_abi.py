@@ -123,3 +123,26 @@ def test_stale_library_is_detected(lib, tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(ImportError, match="built from different sources"):
         _lib.load()
+    # an explicit override downgrades the refusal to a warning
+    monkeypatch.setenv("MA_ALLOW_STALE_LIB", "1")
+    with pytest.warns(UserWarning, match="built from different sources"):
+        assert _lib.load() is not None
+    monkeypatch.delenv("MA_ALLOW_STALE_LIB")
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_source_hash_travels_inside_the_library(lib, tmp_path, monkeypatch):
+    """The hash is compiled into the .so (`ma_version()`): a library without its side file is still recognised as current, and a
+    packaged library with no sources next to it loads without a check."""
+    from meshanything_amd import build as B
+    assert B.embedded_hash() == B.source_hash()
+    assert ("src=" + B.source_hash()) in lib.ma_version().decode()
+    monkeypatch.setattr(B, "HASH_FILE", str(tmp_path / "no_such_side_file"))
+    assert B.recorded_hash() == B.source_hash() and not B.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.load() is not None
+    monkeypatch.setattr(B, "CSRC", str(tmp_path / "no_sources_here"))
+    assert not B.have_sources()
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", None)

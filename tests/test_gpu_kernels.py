@@ -1,5 +1,9 @@
-"""Kernel-level parity (MI355X): each HIP kernel, called through the C ABI (ma_op_*), against a plain PyTorch fp32
-reference of the same op with the same rounding points."""
+"""Kernel-level parity (MI355X): each HIP kernel, called through the C ABI (ma_op_*), against a plain PyTorch fp32 / fp64
+reference of the same op with the same rounding points.
+
+Inputs are drawn and references computed ON THE GPU with stock torch-ROCm ops (seeded device generator; fp64 matmuls / softmax):
+an implementation independent of the HIP library, and nothing here waits for the GPU box's host cores -- on a shared host the
+CPU references of this file alone took 250 s of a driver-style run (profiles/r03_gpu_suite_host_cpu_v0.txt)."""
 import ctypes as C
 import math
 
@@ -12,6 +16,19 @@ pytestmark = pytest.mark.gpu
 
 def _bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _gen(seed):
+    return torch.Generator(device="cuda").manual_seed(int(seed))
+
+
+@pytest.fixture(autouse=True)
+def _tensors_live_on_the_gpu():
+    """Every factory call of a test (randn, linspace, arange, full, ...) creates its tensor on the GPU."""
+    torch.set_default_device("cuda")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+    torch.set_default_device("cpu")
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +52,7 @@ def _stream():
 
 
 def _relerr(got, ref):
-    got, ref = got.double().cpu(), ref.double().cpu()
+    got, ref = got.double(), ref.double()
     return float((got - ref).abs().max() / max(1e-6, float(ref.abs().max())))
 
 
@@ -43,7 +60,7 @@ def _relerr(got, ref):
 @pytest.mark.parametrize("N,K", [(1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096), (8195, 1024), (128, 128), (256, 128), (67, 256), (128, 2048)])
 @pytest.mark.parametrize("variant", ["plain", "ln_relu_res"])
 def test_gemv(lib, wdtype, N, K, variant):
-    g = torch.Generator().manual_seed(N * 7 + K + wdtype)
+    g = _gen(N * 7 + K + wdtype)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     x = torch.randn(K, generator=g) * 1.5 + 0.3
     bias = torch.randn(N, generator=g) * 0.1
@@ -78,7 +95,7 @@ def test_gemv(lib, wdtype, N, K, variant):
                                                (1057, 3072, 768, 2, False), (17, 128, 128, 1, True), (1, 1024, 768, 0, False),
                                                (100, 96, 32, 0, False), (256, 64, 3072, 0, True)])
 def test_gemm(lib, wdtype, impl, M, N, K, act, use_res):
-    g = torch.Generator().manual_seed(M + 3 * N + 5 * K + wdtype)
+    g = _gen(M + 3 * N + 5 * K + wdtype)
     # asymmetric data so that a transposed fragment layout cannot pass
     A = torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5
     W = torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02
@@ -104,7 +121,7 @@ def test_gemm(lib, wdtype, impl, M, N, K, act, use_res):
 
 
 def test_layernorm(lib):
-    g = torch.Generator().manual_seed(3)
+    g = _gen(3)
     for rows, D, eps in ((257, 768, 1e-5), (1057, 768, 1e-12), (5, 1024, 1e-5), (17, 128, 1e-5)):
         x = torch.randn(rows, D, generator=g) * 3 + 1
         gm, bt = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
@@ -112,7 +129,7 @@ def test_layernorm(lib):
         xd, y, gd, bd = x.cuda(), torch.empty(rows, D, device="cuda"), gm.cuda(), bt.cuda()
         _chk(lib, lib.ma_op_layernorm(_p(xd), D, _p(gd), _p(bd), eps, _p(y), D, rows, D, _stream()))
         torch.cuda.synchronize()
-        assert float((y.cpu() - ref).abs().max()) < 2e-5
+        assert float((y - ref).abs().max()) < 2e-5
 
 
 def _attn_ref(q, k, v, scale, causal_offset, rnd, round_p=False):
@@ -138,7 +155,7 @@ def _attn_ref(q, k, v, scale, causal_offset, rnd, round_p=False):
 @pytest.mark.parametrize("Sq,Sk,H,layout,causal", [(257, 4096, 12, "cross", -1), (257, 257, 12, "interleaved", -1), (257, 257, 16, "std", 0),
                                                     (1057, 1057, 12, "std", -1), (17, 17, 2, "std", 0), (70, 130, 2, "std", 60)])
 def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
-    g = torch.Generator().manual_seed(Sq + Sk + H)
+    g = _gen(Sq + Sk + H)
     q = torch.randn(Sq, H, 64, generator=g)
     k = torch.randn(Sk, H, 64, generator=g)
     v = torch.randn(Sk, H, 64, generator=g)
@@ -167,7 +184,7 @@ def test_attention(lib, rnd, Sq, Sk, H, layout, causal):
     torch.cuda.synchronize()
     del args
     assert not torch.isnan(O).any()
-    err = float((O.cpu() - ref).abs().max())
+    err = float((O - ref).abs().max())
     # MFMA kernel: P is rounded relative to the RUNNING row maximum (online softmax), the reference relative to the final
     # one, so individual p differ by one bf16 ulp (2^-9 relative); the weighted average over keys stays well below that
     assert err < (2e-3 if rnd == 1 else 2e-5), err
@@ -180,7 +197,7 @@ def test_decode_attention(lib, kvdtype, length, max_seq, H):
     """Split-KV decode attention (16 equal chunks per head) + the partial merge; repeated launches reuse the same
     workspace and the result must be bit-stable from launch to launch."""
     max_seq = max(max_seq, length)
-    g = torch.Generator().manual_seed(length + H)
+    g = _gen(length + H)
     q = torch.randn(H * 64, generator=g)
     k = torch.randn(H, max_seq, 64, generator=g)
     v = torch.randn(H, max_seq, 64, generator=g)
@@ -199,7 +216,7 @@ def test_decode_attention(lib, kvdtype, length, max_seq, H):
         out = torch.full((H * 64,), float("nan"), device=dev)
         _chk(lib, lib.ma_op_decode_attention(kvdtype, _p(qd), _p(kd), _p(vd), H, max_seq, length, _p(out), _p(ws), _stream()))
         torch.cuda.synchronize()
-        outs.append(out.cpu())
+        outs.append(out)
     assert not torch.isnan(outs[0]).any()
     assert float((outs[0] - ref).abs().max()) < 2e-5
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
@@ -213,7 +230,7 @@ def test_decode_attention_rows(lib, B, length, H, waves):
     cache beyond `length` hold NaN and must not be touched."""
     if waves not in (4, 82) and B * length > 20000 or waves == 82 and B * length > 40000:
         pytest.skip("the large cases run once, with the default block size")
-    g = torch.Generator().manual_seed(B * 7 + length)
+    g = _gen(B * 7 + length)
     max_seq = length + 3
     q = torch.randn(B, H * 64, generator=g)
     k = torch.randn(B, H, max_seq, 64, generator=g)
@@ -226,10 +243,10 @@ def test_decode_attention_rows(lib, B, length, H, waves):
         out = torch.full((B, H * 64), float("nan"), device="cuda", dtype=torch.bfloat16)
         _chk(lib, lib.ma_op_decode_attention_rows(_p(qd), _p(kd), _p(vd), H, max_seq, length, B, H * max_seq * 64, 8 if waves == 82 else waves, 2 if waves == 82 else 1, _p(out), _stream()))
         torch.cuda.synchronize()
-        outs.append(out.cpu())
+        outs.append(out)
     assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
     qb = q.to(torch.bfloat16).float().reshape(B, H, 64)
-    kf, vf = kd.cpu().float()[:, :, :length], vd.cpu().float()[:, :, :length]
+    kf, vf = kd.float()[:, :, :length], vd.float()[:, :, :length]
     p = torch.softmax(torch.einsum("bhd,bhsd->bhs", qb.double(), kf.double()) * 0.125, dim=-1)
     ref = torch.einsum("bhs,bhsd->bhd", p, vf.double()).reshape(B, H * 64).float()
     # output is rounded to bf16 (2^-9 relative); values are O(1)
@@ -245,7 +262,7 @@ def test_gemm_dec_ln(lib, B, N, parts, act, extras):
     partial buffers + bias + residual) rounded to bf16; against fp64 torch on the same rounding point; the LayerNorm output itself
     (the later residual) within fp32 accuracy; bit-stable across launches."""
     K = 1024
-    g = torch.Generator().manual_seed(B + N + parts)
+    g = _gen(B + N + parts)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
     pin = torch.randn(parts, B, K, generator=g) * 0.7 + 3.0            # a large common offset: the shifted statistics must cope
     pb = torch.randn(K, generator=g) * 0.1 if extras else None
@@ -266,7 +283,7 @@ def test_gemm_dec_ln(lib, B, N, parts, act, extras):
         xo = torch.full((B, K), float("nan"), device=dev)
         _chk(lib, lib.ma_op_gemm_dec_ln(_p(Wd), _p(bd), _p(pind), parts, _p(pbd), _p(prd), _p(lgd), _p(lbd), 1e-5, _p(xo), _p(y), _p(yb), N, B, act, _stream()))
         torch.cuda.synchronize()
-        outs.append((y.cpu(), yb.cpu(), xo.cpu()))
+        outs.append((y, yb, xo))
     y, yb, xo = outs[0]
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     assert float((xo.double() - xn).abs().max()) < 2e-5
@@ -285,7 +302,7 @@ def test_gemm_dec(lib, B, N, K, ksplit, act):
     """Skinny bf16 MFMA GEMM of the batched decode step (gemm_decode.hpp) against fp64 torch: every batch-tile count (1-4),
     whole-K and split-K launches (split launches return raw partial sums, summed here), bias / ReLU / residual epilogue,
     fp32 and bf16 outputs."""
-    g = torch.Generator().manual_seed(B + N + 3 * K + ksplit)
+    g = _gen(B + N + 3 * K + ksplit)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02).to(torch.bfloat16)
     X = (torch.randn(B, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(torch.bfloat16)
     bias = torch.randn(N, generator=g) * 0.1
@@ -311,14 +328,14 @@ def test_gemm_dec(lib, B, N, K, ksplit, act):
     torch.cuda.synchronize()
     assert not torch.isnan(y).any()
     assert _relerr(y, full) < 2e-5, _relerr(y, full)
-    assert torch.equal(yb.cpu(), y.cpu().to(torch.bfloat16))          # the bf16 output is the rounded fp32 output
+    assert torch.equal(yb, y.to(torch.bfloat16))          # the bf16 output is the rounded fp32 output
 
 
 @pytest.mark.parametrize("B", [4, 17, 64])
 def test_gemm_dec_qkv_epilogue(lib, B):
     """q rows -> fp32 vector per batch row; k / v rows -> that row's cache planes at `pos` (bf16), nothing else touched."""
     H, heads, max_seq, pos = 1024, 16, 300, 271
-    g = torch.Generator().manual_seed(B)
+    g = _gen(B)
     W = (torch.randn(3 * H, H, generator=g) / math.sqrt(H)).to(torch.bfloat16)
     X = torch.randn(B, H, generator=g).to(torch.bfloat16)
     bias = torch.randn(3 * H, generator=g) * 0.1
@@ -334,7 +351,7 @@ def test_gemm_dec_qkv_epilogue(lib, B):
     assert _relerr(q, ref[:, :H]) < 2e-5
     kref = ref[:, H:2 * H].reshape(B, heads, 64).to(torch.bfloat16)
     vref = ref[:, 2 * H:].reshape(B, heads, 64).to(torch.bfloat16)
-    kgot, vgot = kc[:, :, pos].cpu(), vc[:, :, pos].cpu()
+    kgot, vgot = kc[:, :, pos], vc[:, :, pos]
     # bf16 rounding of values that differ by fp32 summation order may land one ulp apart
     assert float((kgot.float() - kref.float()).abs().max()) <= 2 ** -6 and float((vgot.float() - vref.float()).abs().max()) <= 2 ** -6
     assert float((kgot.float() - kref.float()).abs().mean()) < 1e-4
@@ -349,7 +366,7 @@ def test_rows_prologue(lib, B, pro):
     """Per-row prologue of the batched step: split-K partial sum + bias + residual (+ LayerNorm), or the merge of the
     split-KV attention partials; fp32 and bf16 outputs."""
     K, heads = 1024, 16
-    g = torch.Generator().manual_seed(B + pro)
+    g = _gen(B + pro)
     dev = "cuda"
     xb = torch.zeros(B, K, dtype=torch.bfloat16, device=dev)
     xn = torch.full((B, K), float("nan"), device=dev)
@@ -377,8 +394,8 @@ def test_rows_prologue(lib, B, pro):
                                            None, heads, _p(xn), _p(xb), K, _stream()))
     torch.cuda.synchronize()
     assert not torch.isnan(xn).any()
-    assert float((xn.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
-    assert torch.equal(xb.cpu(), xn.cpu().to(torch.bfloat16))
+    assert float((xn - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(xb, xn.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("M,N,K,act,use_res,out", [(4112, 3072, 1024, 0, False, "bf16"), (4112, 1024, 1024, 0, True, "f32"), (4112, 4096, 1024, 1, False, "bf16"),
@@ -388,7 +405,7 @@ def test_rows_prologue(lib, B, pro):
 def test_gemm_bf16_tile(lib, M, N, K, act, use_res, out):
     """The bf16 policy's dense GEMM (gemm_tile.hpp) on its native bf16 operands at the batched dense-phase shapes (B x 257,
     B x 4096, B x 1057 rows), ragged edges, both tile variants; fp32 and bf16 outputs; reports TFLOP/s."""
-    g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
+    g = _gen(M + 3 * N + 5 * K)
     A = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(torch.bfloat16)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02).to(torch.bfloat16)
     bias = torch.randn(N, generator=g) * 0.1

@@ -8,6 +8,7 @@ import torch
 
 from meshanything_amd.checkpoint import synthetic_state_dict
 from meshanything_amd.config import MAConfig, DTYPE_F32
+from conftest import oracle_device
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def env():
     model2 = MeshAnything(args)
     res = model2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     assert list(res.missing_keys) == [] and list(res.unexpected_keys) == []
-    return types.SimpleNamespace(cfg=cfg, model=model2, oracle=Oracle(cfg, sd, "fp32"))
+    return types.SimpleNamespace(cfg=cfg, model=model2, oracle=Oracle(cfg, sd, "fp32", device=oracle_device()))
 
 
 def _clouds(cfg, seeds):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16
-from conftest import cached_state_dict
+from conftest import cached_state_dict, load_weights_cached
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def eng(golden_dir):
     from meshanything_amd.engine import Engine
     cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=2)
     e = Engine(cfg)
-    e.load_weights(cached_state_dict(cfg).items())
+    load_weights_cached(e, cfg)
     if not e.persist_available():
         pytest.skip("persistent decode step not available on this device (needs 256 CUs)")
     d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
@@ -175,6 +175,40 @@ def test_fused_qkv_attention_launch_is_bitwise_the_two_launches(eng):
             row[fuse] = eng.profile_decode(L, 16)["step_ms_graph"] * 1e3
         eng.set_option("fuse_qkv_attn", 1)
         print(f"[fused qkv+attn A/B] kv_len {L:5d}: two launches {row[0]:7.1f} us/step | fused {row[1]:7.1f} us/step | ratio {row[1] / row[0]:.3f}")
+
+
+def test_fused_launches_fall_back_when_the_device_is_shared(eng):
+    """The fused launches spin on granules written by other blocks of their grid: they need all 256 blocks resident.  Another
+    stream that holds most CUs (here: 250 workgroups with 160 KiB of LDS each, for 0.4 s) breaks that.  The engine must notice (one
+    bounded 20 ms sweep, then every other sweep gives up at once), switch to the five-launch chain -- which needs no co-residency
+    and produces the same bits -- run the generation again and return the SAME tokens, not MA_ERR_HIP."""
+    if eng.get_option("chain_resident") != 1:
+        pytest.skip("the fused launches are not in use on this device")
+    n = 24
+    want, want_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
+    want = want.cpu()
+    base = eng.get_option("chain_fallbacks")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    eng.occupy_cus(250, 400_000, stream=side)                      # 250 of the 256 CUs are gone for 0.4 s
+    got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
+    t1.record(); torch.cuda.synchronize()
+    try:
+        assert eng.get_option("chain_fallbacks") == base + 1, "the starved grid was not noticed"
+        assert eng.get_option("chain_resident") == 0 and eng.get_option("fuse_qkv_attn") == 0 and eng.get_option("fuse_oproj_fc1") == 0
+        assert torch.equal(got.cpu(), want) and list(got_len) == list(want_len)
+        # the engine stays on the five-launch chain (no spinning on a device that has shown to be shared): still the same tokens
+        again, _ = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
+        assert torch.equal(again.cpu(), want)
+        print(f"[fallback] starved generation of {n} tokens took {t0.elapsed_time(t1):.0f} ms incl. one 20 ms bounded sweep and the re-run")
+    finally:
+        side.synchronize()
+        eng.set_option("chain_resident", 1)                          # re-arm for the tests that follow
+    assert eng.get_option("chain_resident") == 1
+    back, _ = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
+    assert torch.equal(back.cpu(), want)
 
 
 @pytest.mark.gpu

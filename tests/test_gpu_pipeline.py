@@ -8,7 +8,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
-from conftest import cached_state_dict
+from conftest import cached_state_dict, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,7 @@ class Env:
         from oracle.meshanything_oracle import Oracle
         self.cfg, self.policy = cfg, policy
         self.sd = cached_state_dict(cfg)
-        self.oracle = Oracle(cfg, self.sd, policy)
+        self.oracle = Oracle(cfg, self.sd, policy, device=oracle_device())
         self.engine = Engine(cfg)
         self.engine.load_weights(self.sd.items())
 
@@ -208,7 +208,7 @@ def test_large_batches_all_mfma_tile_counts(B):
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, "bf16"
     env.sd = cached_state_dict(cfg)
-    env.oracle = Oracle(cfg, env.sd, "bf16")
+    env.oracle = Oracle(cfg, env.sd, "bf16", device=oracle_device())
     env.engine = Engine(cfg)
     env.engine.load_weights(env.sd.items())
     x = clouds(cfg, list(range(100, 100 + B)))
@@ -357,6 +357,21 @@ def test_weights_are_required_and_checked():
     # fp16 / bf16 checkpoint tensors are accepted (converted on load)
     eng3 = Engine(cfg)
     eng3.load_weights(((k, torch.from_numpy(v).to(torch.bfloat16)) for k, v in sd.items()))
+    # large tensors are converted on the device (ma_engine_load_weights), small ones on the host: both must produce the bytes of the
+    # host-only packer (ma_pack_weights_host, what a DP rank 0 would broadcast) -- a 1021-entry codebook makes lm_head (-> bf16) and the
+    # codebook table (-> fp32) large enough for the device path, from fp32, bf16 and fp16 storage
+    from meshanything_amd import dp
+    for dt in (DTYPE_BF16, DTYPE_F32):
+        cfg2 = MAConfig.tiny(dtype=dt, codebook_size=1021)
+        sd2 = synthetic_state_dict(cfg2)
+        assert sd2["transformer.lm_head.weight"].size >= 1 << 16
+        for conv in (lambda v: v, lambda v: torch.from_numpy(v).to(torch.bfloat16), lambda v: v.astype(np.float16)):
+            items = [(k, conv(v)) for k, v in sd2.items()]
+            host = dp.pack_host_arena(cfg2, items)
+            e4 = Engine(cfg2)
+            e4.load_weights(items)
+            assert np.array_equal(e4.arena_tensor().cpu().numpy(), host), "device-side and host-side weight packing disagree"
+            e4.close()
 
 
 # ------------------------------------------------------------------------------------------------ 350M shape
@@ -368,9 +383,9 @@ def full(request):
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, request.param
     env.sd = cached_state_dict(cfg)
-    env.oracle = Oracle(cfg, env.sd, request.param)
+    env.oracle = Oracle(cfg, env.sd, request.param, device=oracle_device())
     env.engine = Engine(cfg)
-    env.engine.load_weights(env.sd.items())
+    load_weights_cached(env.engine, cfg)
     return env
 
 
@@ -493,9 +508,9 @@ def test_v2_scale_1600_faces(golden_dir):
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, "bf16"
     env.sd = cached_state_dict(cfg)
-    env.oracle = Oracle(cfg, env.sd, "bf16")
+    env.oracle = Oracle(cfg, env.sd, "bf16", device=oracle_device())
     env.engine = Engine(cfg)
-    env.engine.load_weights(env.sd.items())
+    load_weights_cached(env.engine, cfg)
     x = mouse_variants(golden_dir, 4)
     prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
     toks, lengths = env.engine.generate(prefix.cuda(), max_new_tokens=96, suppress_eos=True)
