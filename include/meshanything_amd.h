@@ -202,7 +202,9 @@ MA_API int  ma_op_gemm_bf16(const void *A, int lda, const void *W, const float *
                             void *Cb, int ldcb, int M, int N, int K, int act, void *stream);
 MA_API int  ma_op_layernorm(const float *x, int ldx, const float *g, const float *b, float eps, float *y, int ldy,
                             int rows, int D, void *stream);
-/* O[b,q,h*64+d] = softmax(Q K^T * scale) V, head_dim 64, fp32 in/out; strides in elements; round_bf16 rounds q,k,v */
+/* O[b,q,h*64+d] = softmax(Q K^T * scale) V, head_dim 64; strides in elements.  round_bf16: 0 fp32 tensors, exact fp32 kernel | 1 fp32 tensors
+ * rounded to bf16, first-generation matrix-core kernel | 2 fp32 kernel on bf16-rounded q,k,v | 3 bf16 tensors, first-generation kernel |
+ * 4 bf16 tensors, the engine's kernel (csrc/attn2.hpp: packed V^T + swapped-operand 32x32x16 MFMA; all strides multiples of 8) */
 MA_API int  ma_op_attention(const float *Q, int q_rs, int q_hs, const float *K, int k_rs, int k_hs, const float *V, int v_rs,
                             int v_hs, float *O, int o_rs, int Sq, int Sk, int H, float scale, int causal_offset /* <0: none */,
                             int round_bf16, void *stream);
@@ -257,10 +259,10 @@ MA_API int  ma_op_rows_prologue(int pro, const float *x, int nparts, int B, cons
                                 void *xb_out, int K, void *stream);
 
 /* ---- test aid: holds `n_blocks` workgroups of `lds_bytes` of LDS each (163840 = a whole CU) on the device for `microseconds`
- * (bounded: <= 2 s) on `stream`, doing nothing.  Lets a test take CUs away from the engine's stream and check that the fused decode
+ * (bounded: <= 2 s) on `stream`, doing nothing; ends early once `*release` (device-visible host memory, may be NULL) is non-zero.  Lets a test take CUs away from the engine's stream and check that the fused decode
  * launches -- which need their whole grid resident -- fall back to the five-launch chain instead of failing the request.  Has no
  * reference counterpart (the reference never shares a device between streams). */
-MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, void *stream);
+MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, const int32_t *release, void *stream);
 
 /* ---- persistent decode step (csrc/persist.hpp): the whole batch-1 greedy step as ONE resident launch instead of the
  * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()

@@ -11,7 +11,7 @@ import os
 from .config import CMAConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmeshanything_amd.so")
+LIB_PATH = os.path.join(HERE, "libmeshanything_amd_debug.so" if os.environ.get("MA_DEBUG", "") not in ("", "0") else "libmeshanything_amd.so")   # build.py: the debug variant
 
 MA_OK = 0
 ERR_NAMES = {0: "MA_OK", -1: "MA_ERR_INVALID", -2: "MA_ERR_HIP", -3: "MA_ERR_STATE", -4: "MA_ERR_UNKNOWN_TENSOR",
@@ -83,7 +83,7 @@ SIGNATURES = {
     "ma_op_gemm_dec_ln": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, C.c_float, _P, _P, _P, _I, _I, _I, _P]),
     "ma_op_gemm_dec_qkv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_size_t, _P]),
     "ma_op_rows_prologue": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _P]),
-    "ma_op_occupy_cus": (_I, [_I, _I, C.c_int64, _P]),
+    "ma_op_occupy_cus": (_I, [_I, _I, C.c_int64, _P, _P]),
     "ma_engine_persist_available": (_I, [_P]),
     "ma_persist_trace": (_I, [_P, _I, _P, C.POINTER(C.c_int32), _P]),
     "ma_engine_read_logits": (_I, [_P, _I, _P, _P]),

@@ -18,11 +18,22 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libmeshanything_amd.so")
-HASH_FILE = OUT + ".srchash"
 SOURCES = ["engine.hip"]
 HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "meshanything_amd.h"))
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-result"]
+# MA_DEBUG=1 selects the debug variant ("race detection / sanitizers"): -O1 -g, device-side assert()s alive
+# (the release build defines NDEBUG), its own file name so the two never shadow each other; `_lib.load()` follows the same variable.
+# MA_DEBUG=asan additionally asks for HIP AddressSanitizer (host + device instrumentation; needs an xnack+ capable setup).
+DEBUG = os.environ.get("MA_DEBUG", "") not in ("", "0")
+ASAN = os.environ.get("MA_DEBUG", "") == "asan"
+OUT = os.path.join(HERE, "libmeshanything_amd_debug.so" if DEBUG else "libmeshanything_amd.so")
+HASH_FILE = OUT + ".srchash"
+_COMMON = ["-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-result"]
+if ASAN:
+    FLAGS = ["--offload-arch=gfx950:xnack+", "-O1", "-g", "-fsanitize=address", "-shared-libsan", "-DMA_DEBUG=1"] + _COMMON
+elif DEBUG:
+    FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-DMA_DEBUG=1"] + _COMMON
+else:
+    FLAGS = ["--offload-arch=gfx950", "-O3", "-DNDEBUG"] + _COMMON
 
 
 def source_files():

@@ -1,0 +1,252 @@
+// Dense attention of the bf16 policy, second generation: O = softmax_fp32(Q K^T * scale) V on the matrix cores with the
+// "swapped" formulation, head_dim 64.  Same reference call sites as attn.hpp (QKVMultiheadAttention / QKVMultiheadCrossAttention,
+// transformer_blocks.py:56-74, 166-185; [3p] flash_attn prefill, shape_opt.py:403-410; [3p] BERT self-attention, meshanything.py:62-64).
+//
+// Why a second kernel: attention_mfma_kernel (attn.hpp) spent the dense phases' time, not the GEMM -- 52 % of it at 8.6 % matrix-core
+// busy at batch 64 (profiles/r02_pmc_dense_mfma.json): V was transposed through LDS with 2-byte stores every tile, P went through
+// LDS, three block barriers per 64-key tile, no load under compute, 64-row blocks that each re-staged the same K / V.
+//
+// Structure (MI355X guide, "Fused attention prefill"):
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16: A = a K tile (keys x d) read from LDS with ds_read_b128, B = the wave's 32 query
+//     rows, held in registers for the whole block.  In the accumulator layout a LANE owns ONE query (column lane & 31) and 32 of the
+//     tile's 64 keys, its partner lane ^ 32 the other 32: the online softmax is 32 register operations plus ONE cross-lane exchange
+//     per tile (the row maximum); the row sum stays a per-lane partial until the end.
+//   * O^T = V^T P^T: P^T is already in the B-operand register layout (column = query) -- converted to bf16 in place, never touching
+//     LDS; the k-index of the contraction is permuted to the order in which the accumulator holds the keys ({0-3, 8-11 | 4-7, 12-15}
+//     of every 16), and V^T is STORED in that order by the kernel that produces it (vt_pack_kernel below: V arrives row-major from
+//     the q/k/v GEMM; the transposition costs one pass over 2-byte data instead of 16 two-byte LDS stores per thread and tile).
+//     A = the V^T tile (d x keys) from LDS, again one ds_read_b128 per MFMA.
+//   * one block = NW waves x 32 query rows (NW = 3 for the 257-row sequences: 96-row blocks waste 11 %, 128-row blocks a third of their
+//     staging), K / V^T tiles of 64 keys in a double-buffered LDS ring filled through registers: the global loads of tile t + 1 are
+//     issued before the 16 MFMAs of tile t and written to the other buffer after them -- ONE barrier per tile;
+//   * both tiles are [64 rows][128 bytes] with the 16-byte chunk index XOR (row >> 1) & 7: conflict-free for the hardware's 16-lane
+//     ds_read_b128 groups when the 32 lanes of a half-wave read 32 different rows (checked by enumeration);
+//   * the output leaves through a per-wave LDS patch so that a row is stored as whole 128-byte lines.
+// Arithmetic: scores, softmax statistics and the output accumulate in fp32; Q, K, V and the probabilities that multiply V are bf16 (the
+// policy's rounding points, oracle/meshanything_oracle.py `attention(dense=True)`); exp is v_exp_f32 on log2-scaled scores.
+// Algorithmic FLOPs: 4 Sq Sk 64 per head.
+#pragma once
+#include "attn.hpp"
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace ma {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Attn2Args {
+    const bf16_t* Q; int q_rs, q_hs;
+    const bf16_t* K; int k_rs, k_hs;
+    const bf16_t* VT;                   // packed V^T: [batch][H][64][skp] (vt_pack_kernel), skp = Sk rounded up to 64
+    bf16_t* O; int o_rs;
+    int Sq, Sk, skp, H;
+    float scale;
+    int causal_offset;                  // < 0: full attention; else query i sees keys <= causal_offset + i
+    size_t q_bs, k_bs, o_bs;            // element strides between the samples of a batch (grid.z)
+};
+
+__device__ __forceinline__ int a2_slot(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// two floats -> packed bf16 (round to nearest even; v_cvt_pk_bf16_f32 on gfx950), element 0 in the low half
+typedef float a2_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 a2_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t a2_pack(float lo, float hi_) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(a2_f32x2{lo, hi_}, a2_bf16x2));
+}
+
+// V (Sk rows x 64 d per head, row stride v_rs, head offset h * v_hs) -> V^T [batch][H][64][skp], zero beyond Sk, the keys of every
+// aligned 16 stored in the order {0-3, 8-11, 4-7, 12-15}.  One block = one 64-key tile of one (sample, head).
+__global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__ V, int v_rs, int v_hs, size_t v_bs, bf16_t* __restrict__ VT, int Sk, int skp, int H) {
+    __shared__ bf16_t t[64][66];        // [key][d], padded: the column reads below walk the keys
+    const int tid = threadIdx.x, h = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 64;
+    const bf16_t* vp = V + (size_t)b * v_bs + (size_t)h * v_hs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, kr = id >> 3, c = id & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (k0 + kr < Sk) v = *reinterpret_cast<const u32x4*>(vp + (size_t)(k0 + kr) * v_rs + c * 8);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t[kr][c * 8 + 2 * j] = (bf16_t)(w4[j] & 0xffffu); t[kr][c * 8 + 2 * j + 1] = (bf16_t)(w4[j] >> 16); }
+    }
+    __syncthreads();
+    bf16_t* op = VT + ((size_t)b * H + h) * 64 * skp + k0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, d = id >> 3, c = id & 7;       // output chunk c of row d: positions 8c .. 8c + 7 of the tile
+        const int g = c >> 1, half = c & 1;                          // 16-key group, which half of its permuted order
+        uint32_t w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p0 = 2 * j, p1 = 2 * j + 1;                    // positions inside the half -> keys {0-3, 8-11} | {4-7, 12-15}
+            const int ka = 16 * g + 4 * half + (p0 & 3) + 8 * (p0 >> 2), kb = 16 * g + 4 * half + (p1 & 3) + 8 * (p1 >> 2);
+            w4[j] = (uint32_t)t[ka][d] | ((uint32_t)t[kb][d] << 16);
+        }
+        *reinterpret_cast<u32x4*>(op + (size_t)d * skp + c * 8) = u32x4{w4[0], w4[1], w4[2], w4[3]};
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
+    constexpr int NT = NW * 64, RB = NW * 32, TILE = 64 * 128;         // threads, query rows per block, bytes of one K or V^T tile
+    constexpr int NCH = (512 + NT - 1) / NT;                            // 16-byte chunks per thread, tile and operand
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // ring of two stages x {K, V^T}; reused for the output patches
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * RB;
+    const bf16_t* Qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
+    const bf16_t* Kp = a.K + (size_t)b * a.k_bs + (size_t)h * a.k_hs;
+    const bf16_t* Vp = a.VT + ((size_t)b * a.H + h) * 64 * a.skp;
+    const int qrow = q0 + w * 32 + ln;                                  // this lane's query
+    const bool qok = qrow < a.Sq;
+
+    // Q^T fragments: B[k = d][n = query]: lane (query ln, k group hi) holds d = 16 s + 8 hi .. + 7 for the four 16-deep steps
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = Qp + (size_t)(qok ? qrow : 0) * a.q_rs + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (qok) v = *reinterpret_cast<const u32x4*>(qp + 16 * s);
+            qf[s] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    int kv_end = a.Sk;
+    if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + RB - 1, a.Sq - 1) + 1);
+    const int nt = (kv_end + 63) >> 6;
+
+    u32x4 kreg[NCH], vreg[NCH];
+    auto gload = [&](int t) {
+        const int kv0 = t << 6;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + NT * i, r = id >> 3, c = id & 7;
+            kreg[i] = u32x4{0u, 0u, 0u, 0u}; vreg[i] = u32x4{0u, 0u, 0u, 0u};
+            if (NT * NCH == 512 || id < 512) {
+                if (kv0 + r < a.Sk) kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)(kv0 + r) * a.k_rs + c * 8);
+                vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)r * a.skp + kv0 + c * 8);
+            }
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* kb = smem + stage * 2 * TILE;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + NT * i, r = id >> 3, c = id & 7;
+            if (NT * NCH == 512 || id < 512) {
+                *reinterpret_cast<u32x4*>(kb + r * 128 + a2_slot(r, c) * 16) = kreg[i];
+                *reinterpret_cast<u32x4*>(kb + TILE + r * 128 + a2_slot(r, c) * 16) = vreg[i];
+            }
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float mrun = -1e30f, lsum = 0.f;
+    const float sc2 = a.scale * 1.44269504088896340736f;               // scores in the log2 domain: exp(x) = exp2(x log2 e)
+
+    if (nt > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) gload(t + 1);                                   // flies under this tile's MFMAs
+        const char* kb = smem + (t & 1) * 2 * TILE;
+        const char* vb = kb + TILE;
+        // ---- S^T = K Q^T: two 32-key blocks x four 16-deep steps ---------------------------------------------------------------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sacc[0][i] = 0.f; sacc[1][i] = 0.f; }
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            const int r = kbk * 32 + ln;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
+                sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kbk], 0, 0, 0);
+            }
+        }
+        // ---- online softmax on the lane's 32 keys of its query: key = 64 t + 32 kbk + (i & 3) + 8 (i >> 2) + 4 hi ----------------------
+        const int kbase = (t << 6) + 4 * hi;
+        const int klimit = a.causal_offset >= 0 ? min(a.Sk - 1, a.causal_offset + qrow) : a.Sk - 1;       // last visible key
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kbase + 32 * kbk + (i & 3) + 8 * (i >> 2);
+                const float v = key <= klimit ? sacc[kbk][i] * sc2 : -INFINITY;
+                sacc[kbk][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                         // the partner lane holds the query's other 32 keys
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        mrun = mnew;
+        float ps = 0.f;
+        bf16x8_t pf[4];                                                 // P^T as B fragments: slice s = keys 16 s .. 16 s + 15 of the tile
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e0 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j] - mnew);        // exp2(-inf) = 0: masked keys drop out
+                const float e1 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j + 1] - mnew);
+                ps += e0 + e1;
+                w4[j] = a2_pack(e0, e1);
+            }
+            pf[s] = __builtin_bit_cast(bf16x8_t, u32x4{w4[0], w4[1], w4[2], w4[3]});
+        }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        // ---- O^T += V^T P^T: four 16-key slices x two 32-row d blocks ------------------------------------------------------------------
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int r = db * 32 + ln;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) lstore((t + 1) & 1);                            // the other stage: last read during tile t - 1, before the previous barrier
+        __syncthreads();
+    }
+    // ---- epilogue: normalise, round, and store whole rows through this wave's LDS patch (32 rows x 128 bytes) ----------------------------
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+    char* patch = smem + w * 4096;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                   // registers 4 j .. 4 j + 3: d = 32 db + 8 j + 4 hi + 0 .. 3
+            u32x2 pk;
+            pk.x = a2_pack(oacc[db][4 * j] * inv, oacc[db][4 * j + 1] * inv);
+            pk.y = a2_pack(oacc[db][4 * j + 2] * inv, oacc[db][4 * j + 3] * inv);
+            *reinterpret_cast<u32x2*>(patch + ln * 128 + a2_slot(ln, 4 * db + j) * 16 + 8 * hi) = pk;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the patch is private to the wave: its LDS queue is in order, no barrier needed
+    bf16_t* Op = a.O + (size_t)b * a.o_bs + (size_t)h * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = lane + 64 * i, r = id >> 3, c = id & 7, row = q0 + w * 32 + r;
+        if (row < a.Sq) *reinterpret_cast<u32x4*>(Op + (size_t)row * a.o_rs + c * 8) = *reinterpret_cast<const u32x4*>(patch + r * 128 + a2_slot(r, c) * 16);
+    }
+}
+
+inline size_t attn2_vt_elems(int Sk, int H, int batch) { return (size_t)batch * H * 64 * ((Sk + 63) & ~63); }
+
+// V^T packing + attention.  `vt` = workspace of attn2_vt_elems(Sk, H, batch) bf16 elements.
+inline hipError_t launch_attention2(const AttnArgs& a, bf16_t* vt, hipStream_t s) {
+    if (a.Sq <= 0 || a.Sk <= 0) return hipSuccess;
+    const int skp = (a.Sk + 63) & ~63;
+    if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_hs | a.k_hs | a.v_hs) % 8) return hipErrorInvalidValue;      // 16-byte vector accesses
+    hipLaunchKernelGGL(vt_pack_kernel, dim3(skp / 64, a.H, a.batch), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(a.V), a.v_rs, a.v_hs, a.v_bs, vt, a.Sk, skp, a.H);
+    Attn2Args g{reinterpret_cast<const bf16_t*>(a.Q), a.q_rs, a.q_hs, reinterpret_cast<const bf16_t*>(a.K), a.k_rs, a.k_hs, vt, reinterpret_cast<bf16_t*>(a.O), a.o_rs,
+                a.Sq, a.Sk, skp, a.H, a.scale, a.causal_offset, a.q_bs, a.k_bs, a.o_bs};
+    // 96-row blocks when they waste fewer rows than 128-row blocks (257 rows: 288 vs 384)
+    const int pad3 = (a.Sq + 95) / 96 * 96, pad4 = (a.Sq + 127) / 128 * 128;
+    if (pad3 < pad4) hipLaunchKernelGGL(attention_mfma2_kernel<3>, dim3(pad3 / 96, a.H, a.batch), dim3(192), 0, s, g);
+    else hipLaunchKernelGGL(attention_mfma2_kernel<4>, dim3(pad4 / 128, a.H, a.batch), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace ma

@@ -92,7 +92,11 @@ __device__ inline float group_sum(float v) {
 
 // ---- LayerNorm of one row, one barrier -------------------------------------------------------------------------------------
 // Both moments are accumulated on the shifted data d = x - x0 (x0 = element 0 of the row, the same value in every thread), so
-// var = E[d^2] - E[d]^2 loses nothing to cancellation however large the row's mean is.  The three pieces below are shared by
+// var = E[d^2] - E[d]^2 does not cancel when the row has a large MEAN (x0 is then close to it).  It is not immune to x0 itself being
+// an outlier: a shift that sits D standard deviations off the mean costs about D^2 * 2^-22 of relative accuracy in the variance
+// (D = 30: 2e-4, below the bf16 rounding of the consumer; D = 100: 2e-3; tests/test_gpu_kernels.py::test_layernorm_prologue_with_an_
+// outlier_in_dim_0 measures it).  The streams normalised here are post-LN (OPT-350m: do_layer_norm_before = False): LayerNorm output
+// plus one sub-layer's update, so a 100-sigma element would have to come out of a single out_proj / fc2 row.  The three pieces below are shared by
 // the block-level prologues (gemv.hpp, gemm_decode.hpp) and the persistent decode kernel (persist.hpp), written with explicit
 // fmaf so that every path produces the same bits: chunk moments -> per-wave sums (wave_sum) -> (red[0]+red[1])+(red[2]+red[3]).
 __device__ __forceinline__ void ln_chunk_moments(f32x4& x, float x0, float& s, float& q) {      // x <- x - x0; adds the chunk's sums

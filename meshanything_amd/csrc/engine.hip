@@ -20,6 +20,7 @@
 
 #include "../../include/meshanything_amd.h"
 #include "attn.hpp"
+#include "attn2.hpp"
 #include "attn_decode.hpp"
 #include "common.hpp"
 #include "dense_ops.hpp"
@@ -121,8 +122,11 @@ struct ma_engine {
     int opt_fuse_fc2 = 1;                // fc2 inside the out_proj + fc1 launch (second in-launch all-gather, 4096 values)
     int opt_oproj_fc1_sweep_waves = 4;   // fused out_proj + fc1 launch: waves per block polling the y1 granules (each its own quarter)
     int opt_gemm_xcd_swizzle = 1;    // dense GEMM: hand the tiles out XCD-aware (gemm_tile.hpp)
+    int opt_attn_impl = 2;           // bf16 dense attention: 2 = swapped-operand 32x32x16 kernel on packed V^T (attn2.hpp), 1 = attention_mfma_kernel (attn.hpp)
+    bf16_t* a_vt = nullptr; size_t vt_elems = 0;      // its V^T workspace
     int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
+    int opt_qkv_xcd_local = 1;       // fused q/k/v + attention launch: the 16 blocks of a head on one XCD (qkv_attn.hpp qkv_block_role)
     int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
@@ -216,7 +220,10 @@ void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, c
                int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0) {
     AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 3 : 0};
     a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
-    HIP_CHECK(launch_attention(a, s));
+    if (e->bf16 && e->opt_attn_impl == 2) {
+        if (attn2_vt_elems(Sk, H, batch) > e->vt_elems) throw MaError(MA_ERR_INVALID, "internal: V^T workspace too small");
+        HIP_CHECK(launch_attention2(a, e->a_vt, s));
+    } else HIP_CHECK(launch_attention(a, s));
 }
 // fp32 stream rows (row map in, optional row mask) -> activation tensor
 void cvt_rows(ma_engine* e, hipStream_t s, const float* src, int lds, RowMap in, const unsigned char* mask, void* dst, int ldd, int rows, int cols) {
@@ -503,6 +510,7 @@ QkvAttnArgs make_qkv_attn_args(ma_engine* e, int l, const float* x_in, const flo
     a.kcache = reinterpret_cast<bf16_t*>(e->kplane(rw.r0, l)); a.vcache = reinterpret_cast<bf16_t*>(e->vplane(rw.r0, l)); a.max_seq = e->maxseq; a.hidden = H;
     a.st = e->d_st + r0; a.len_override = len_override; a.layer = l; a.ws = e->d_part + r0 * attn_workspace_floats(c.heads); a.gran = e->d_qkv_gran + r0 * 3 * H; a.err = e->d_chain_err;
     a.x_stride = H; a.xn_stride = H; a.kv_row_stride = e->kv_row_bytes / e->kv_elem;
+    a.xcd_local = e->opt_qkv_xcd_local;
     return a;
 }
 OprojFc1Args make_oproj_fc1_args(ma_engine* e, int l, const float* resid, Rows rw, bool with_fc2) {
@@ -1068,6 +1076,11 @@ void build_engine(ma_engine* e) {
     e->w_fe = e->dmalloc<float>(R * e->nf * Wt); e->w_logit = e->dmalloc<float>(R * e->nf * 9 * c.discrete_num);
     e->w_mask = e->dmalloc<unsigned char>(R * e->nf);
     e->a_feat = amalloc(R * N * 64); e->a_dataln = amalloc(R * N * W); e->a_kv = amalloc(R * N * 2 * W); e->a_q = amalloc((size_t)T * W);
+    if (e->bf16) {
+        size_t v = attn2_vt_elems(N, c.enc_heads, (int)R);
+        v = std::max(v, attn2_vt_elems(T, c.enc_heads, (int)R)); v = std::max(v, attn2_vt_elems(T, c.heads, (int)R)); v = std::max(v, attn2_vt_elems(S, c.tok_heads, (int)R));
+        e->vt_elems = v; e->a_vt = e->dmalloc<bf16_t>(v);
+    }
     e->a_ln = amalloc(rows_seq * wmax); e->a_qkv = amalloc(rows_seq * 3 * wmax); e->a_att = amalloc(rows_seq * wmax); e->a_mlp = amalloc(rows_seq * fmax);
     e->a_cat = amalloc(R * NL * 2 * W); e->a_mean = amalloc(R * NL * c.embed_dim); e->a_fein = amalloc(R * e->nf * 3 * c.codebook_dim);
     e->a_x = amalloc(R * S * Wt);
@@ -1178,9 +1191,11 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
         else if (n == "fuse_fc2") { e->opt_fuse_fc2 = (int)value; drop_graphs(e); }
+        else if (n == "qkv_xcd_local") { e->opt_qkv_xcd_local = value ? 1 : 0; drop_graphs(e); }
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
+        else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
         else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
         else if (n == "gemv_small_rows") {
             if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_small_rows must be 0, 1, 2 or 4");
@@ -1229,9 +1244,11 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
         else if (n == "fuse_fc2") *value = e->opt_fuse_fc2;
+        else if (n == "qkv_xcd_local") *value = e->opt_qkv_xcd_local;
         else if (n == "fuse_layer") *value = fuse_layer(e) ? 1 : 0;
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
+        else if (n == "attn_impl") *value = e->opt_attn_impl;
         else if (n == "gemm_variant") *value = gemm_tile_variant();
         else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
@@ -1574,7 +1591,17 @@ int ma_op_attention(const float* Q, int q_rs, int q_hs, const float* K, int k_rs
     return guarded(nullptr, [&] {
         if (!Q || !K || !V || !O) throw MaError(MA_ERR_INVALID, "ma_op_attention: null pointer");
         AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, V, v_rs, v_hs, O, o_rs, Sq, Sk, H, scale, causal_offset, round_bf16};
-        HIP_CHECK(launch_attention(a, reinterpret_cast<hipStream_t>(stream)));
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        if (round_bf16 == 4) {                               // bf16 tensors, the engine's default kernel (attn2.hpp): V^T packing + swapped-operand attention
+            bf16_t* vt = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&vt), attn2_vt_elems(Sk, H, 1) * sizeof(bf16_t)));
+            hipError_t r = launch_attention2(a, vt, s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(vt);
+            if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_attention: ") + hipGetErrorString(r));
+            return;
+        }
+        HIP_CHECK(launch_attention(a, s));
     });
 }
 
@@ -1686,13 +1713,13 @@ int ma_op_rows_prologue(int pro, const float* x, int nparts, int B, const float*
     });
 }
 
-int ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, void* stream) {
+int ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, const int32_t* release, void* stream) {
     return guarded(nullptr, [&] {
         if (n_blocks < 1 || n_blocks > 4096 || lds_bytes < 64 || lds_bytes > 160 * 1024 || microseconds < 1 || microseconds > 2000000)
             throw MaError(MA_ERR_INVALID, "ma_op_occupy_cus: bad arguments");
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(64), (size_t)lds_bytes, reinterpret_cast<hipStream_t>(stream), (unsigned long long)microseconds * 100ull,
-                           (unsigned*)nullptr);
+                           reinterpret_cast<const int*>(release), (unsigned*)nullptr);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -38,6 +38,8 @@ struct GemmTArgs {
     int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
     RowMap cmap;                    // output row of logical row m
     int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
+    int m_begin;                    // first row this launch computes (rows [m_begin, M)): launch_gemm_tile peels a ragged tail of rows off
+                                    // into a second launch so that the bulk fills whole rounds of resident blocks
 };
 
 __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
@@ -49,7 +51,13 @@ __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
 template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // BM x BN x BK block tile, 4 waves as 2 x 2.  LDS: NS stages x (BM + BN) rows x BK bf16.
-template <int BM, int BN, int BK, int NS>
+// RAW: the K-loop's barrier is a bare s_barrier behind `s_waitcnt lgkmcnt(0)` instead of __syncthreads().  With an LDS-DMA in flight
+// __syncthreads() carries `vmcnt(0)` (the DMA is a pending LDS write on the VM counter; MI355X guide section 5, "Pipelining across
+// barriers"), which drains the ring at every K-tile -- the reason the deeper rings of round 2 measured slower, not faster.  The raw
+// form keeps the younger tiles flying across the barrier; what it must still order is covered explicitly: this wave's own pieces of
+// tile kt by the counted vmcnt, everyone's by the barrier behind it, and the stage that is re-filled was read one iteration earlier
+// (its ds_reads retired by the lgkmcnt(0) in front of this barrier).
+template <int BM, int BN, int BK, int NS, bool RAW = false>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
     auto swz = [](int r) { return CH == 8 ? (r & 7) : ((r >> 1) & 3); };
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
         const int t = xcd * lo + min(xcd, rem) + i;
         tile_y = t / NT; tile_x = t - tile_y * NT;
     }
-    const int bm = tile_y * BM, bn = tile_x * BN;
+    const int bm = g.m_begin + tile_y * BM, bn = tile_x * BN;
     const unsigned lds0 = (unsigned)(size_t)gt_smem;
 
     // ---- DMA addressing: instruction p of an operand covers tile rows p * RPI .. + RPI - 1; lane -> (row, slot) -----------
@@ -113,7 +121,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + PF <= nk) gt_wait_vm<(PF - 1) * IPW>();       // this wave's pieces of K-tile kt have landed (younger tiles still fly) ...
         else gt_wait_vm<0>();
-        __syncthreads();                                       // ... and everyone's; the stage read last iteration is free
+        if constexpr (RAW) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        else __syncthreads();                                  // ... and everyone's; the stage read last iteration is free
         if (kt + PF < nk) issue(kt + PF, stage == 0 ? NS - 1 : stage - 1);
         const char* sa = gt_smem + stage * STAGE;
         const char* sw = sa + A_BYTES;
@@ -181,19 +190,20 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
 }
 
 // variant knob (engine option gemm_variant; A/B in profiles/): 0 = K-tile 64, 2 stages | 1 = K-tile 32, 4 stages | 2 = K-tile 32, 5 stages |
-// 3 = K-tile 64, 3 stages (one block per CU)
-inline int& gemm_tile_variant() { static int v = 0; return v; }
+// 3 = K-tile 64, 3 stages (one block per CU) | 4 = K-tile 64, 3 stages, raw barrier | 5 = K-tile 32, 4 stages, raw barrier | 6 = K-tile 64,
+// 2 stages, raw barrier (default) | 7 = K-tile 32, 6 stages, raw barrier | 8 = the 128 x 64 tile for every shape (A/B of the tail rounds)
+inline int& gemm_tile_variant() { static int v = 6; return v; }      // 6: +2 ... +13 % over 0 on the path's shapes (profiles/r03_ab_dense_attention_gemm_variants.txt)
 
-template <int BM, int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS, bool RAW = false>
 inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static bool attr = false;
     if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW>), dim3((g.N + BN - 1) / BN, (g.M - g.m_begin + BM - 1) / BM), dim3(256), LDS, s, g);
     return hipGetLastError();
 }
 
@@ -203,16 +213,30 @@ inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
     const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
     const int v = gemm_tile_variant();
+    if (v == 8 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 2, true>(g, s);      // A/B: the half tile everywhere
+    if (v == 9 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 3, true>(g, s);     // A/B: 48 KB of LDS: three blocks per CU
+    if (v == 10 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 3, true>(g, s);     // A/B: half tile, two K-tiles in flight
+    if (v == 11 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 2, true>(g, s);    // A/B: 32 KB of LDS: four-five blocks per CU
+    // OPT-prefill shapes (K = hidden | ffn, N >= hidden, M = B x 257): the 32 KB-of-LDS form (K-tile 32, four to five blocks per CU) hides the
+    // per-tile latency better than two 64 KB blocks: 60 vs 70 us (N = K = 1024), 205 vs 262 us (N = 4096), 178 vs 190 us (K = 4096) at M = 16448
+    // (profiles/r03_ab_gemm_tile_occupancy_and_tail.txt); K = 768 shapes and very tall problems prefer the 64 KB form
+    if (v == 6 && g.K % 64 == 0 && g.K >= 1024 && g.N >= 1024 && g.M > 64 && g.M <= 32768 && tiles128 >= 160) return gt_launch<128, 128, 32, 2, true>(g, s);
     if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) {
         if (v == 1) return gt_launch<128, 128, 32, 4>(g, s);
         if (v == 2) return gt_launch<128, 128, 32, 5>(g, s);
         if (v == 3) return gt_launch<128, 128, 64, 3>(g, s);
-        return gt_launch<128, 128, 64, 2>(g, s);
+        if (v == 4) return gt_launch<128, 128, 64, 3, true>(g, s);
+        if (v == 5) return gt_launch<128, 128, 32, 4, true>(g, s);
+        if (v == 6) return gt_launch<128, 128, 64, 2, true>(g, s);
+        if (v == 7) return gt_launch<128, 128, 32, 6, true>(g, s);
+        if (v == 0) return gt_launch<128, 128, 64, 2>(g, s);
+        return gt_launch<128, 128, 64, 2, true>(g, s);
     }
     if (g.K % 64 == 0 && g.M > 64 && g.N > 32) {      // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
         if (v == 1 || v == 2) return gt_launch<128, 64, 32, 5>(g, s);
         if (v == 3) return gt_launch<128, 64, 64, 3>(g, s);
-        return gt_launch<128, 64, 64, 2>(g, s);
+        if (v == 0) return gt_launch<128, 64, 64, 2>(g, s);
+        return gt_launch<128, 64, 64, 2, true>(g, s);
     }
     return gt_launch<64, 64, 32, 2>(g, s);
 }

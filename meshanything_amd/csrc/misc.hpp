@@ -227,11 +227,14 @@ __global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, i
 }
 
 // test aid (ma_op_occupy_cus): a workgroup that holds its dynamic LDS allocation and sleeps until `ticks` of the 100 MHz counter passed
-__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, unsigned* sink) {
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, const int* release, unsigned* sink) {
     extern __shared__ char occupy_lds[];
     occupy_lds[threadIdx.x] = 1;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // the host let go
+        __builtin_amdgcn_s_sleep(64);
+    }
     if (occupy_lds[threadIdx.x] == 2 && sink) *sink = 1;       // never true: keeps the allocation alive
 }
 

@@ -36,6 +36,7 @@ struct QkvAttnArgs {
     unsigned* err;
     int x_stride, xn_stride; size_t kv_row_stride;
     unsigned long long* trace;
+    int xcd_local;                                       // 1: the 16 blocks of a head are dispatched to ONE XCD (see qkv_block_role)
 };
 constexpr unsigned QA_ERR_GATHER = 16;
 
@@ -225,10 +226,25 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     }
 }
 
+// (chunk, head) of a block.  Workgroups go to the 8 XCDs round-robin in dispatch order (observed, never relied upon: MI355X guide,
+// "Workgroup dispatch"), i.e. block L = x + 16 y lands on XCD L % 8.  With the plain role (chunk x, head y) the 16 blocks of a head sit
+// on all eight XCDs and the q/k/v exchange among them crosses the fabric; remapped, XCD i runs heads i and i + 8 (two times 16 blocks):
+// publisher and poller of a granule share an L2 (hand-off +0.1-0.3 us cheaper per hop, guide row handoff-1to1).  A speed choice only:
+// the exchange protocol does not care where a block runs.
+__device__ __forceinline__ void qkv_block_role(const QkvAttnArgs& a, int& c, int& h) {
+    c = blockIdx.x; h = blockIdx.y;
+    if (a.xcd_local && (gridDim.y & 7) == 0) {
+        const int L = blockIdx.x + ATTN_NCHUNK * blockIdx.y, xcd = L & 7, j = L >> 3;
+        h = xcd + 8 * (j / ATTN_NCHUNK); c = j % ATTN_NCHUNK;
+    }
+}
+
 template <int PRO>
 __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     QkvOperands op;
-    qkv_attn_body<PRO, false>(a, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z, nullptr, op);
+    int c, h;
+    qkv_block_role(a, c, h);
+    qkv_attn_body<PRO, false>(a, c, h, gridDim.y, blockIdx.z, nullptr, op);
 }
 
 inline hipError_t launch_qkv_attn(const QkvAttnArgs& a, int heads, int batch, hipStream_t s) {

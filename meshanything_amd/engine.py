@@ -267,11 +267,15 @@ class Engine:
         self.last_compute_trace = out[256 * 320:].reshape(256, 512)
         return out[:256 * 320].reshape(256, 320)[:, :n.value]
 
-    def occupy_cus(self, n_blocks: int, microseconds: int, stream: Optional[torch.cuda.Stream] = None, lds_bytes: int = 160 * 1024) -> None:
+    def occupy_cus(self, n_blocks: int, microseconds: int, stream: Optional[torch.cuda.Stream] = None, lds_bytes: int = 160 * 1024,
+                   release: Optional[torch.Tensor] = None) -> None:
         """Test aid (ma_op_occupy_cus): park `n_blocks` workgroups holding `lds_bytes` of LDS each (default: a whole CU) on `stream` for
-        `microseconds`, so that a test can take CUs away from the engine's own stream."""
+        `microseconds` -- or until `release` (a pinned int32 host tensor the caller sets to non-zero) says so -- so that a test can take
+        CUs away from the engine's own stream."""
         sp = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
-        self._check(self.lib.ma_op_occupy_cus(int(n_blocks), int(lds_bytes), int(microseconds), sp))
+        if release is not None:
+            assert release.dtype == torch.int32 and release.is_pinned()
+        self._check(self.lib.ma_op_occupy_cus(int(n_blocks), int(lds_bytes), int(microseconds), _ptr(release), sp))
 
     # ---------------------------------------------------------------- measurement
     def profile_decode(self, kv_len: int, steps: int = 4) -> Dict[str, object]:

@@ -9,8 +9,10 @@ from meshanything_amd.engine import Engine
 lib = _lib.load()
 eng = Engine(MAConfig.tiny(dtype=DTYPE_BF16))
 p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-shapes = [(4112, 1024, 1024), (16448, 768, 768), (16448, 1024, 1024), (16448, 4096, 1024), (16448, 1024, 4096), (16448, 3072, 1024), (65536, 1024, 1024),
-          (67648, 768, 768), (67648, 3072, 768), (67648, 768, 3072), (8192, 8192, 8192)]
+shapes = [(16448, 768, 768), (16384, 768, 768), (16448, 1024, 1024), (16384, 1024, 1024), (16448, 4096, 1024), (16448, 1024, 4096), (16384, 1024, 4096), (16448, 3072, 1024),
+          (16448, 2304, 768), (16448, 768, 3072), (16384, 768, 3072), (67648, 768, 768), (67648, 3072, 768), (262144, 1536, 768), (8192, 8192, 8192)]
+if os.environ.get("GEMM_SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["GEMM_SHAPES"].split(",")]
 variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,2").split(",")]
 for v in variants:
     eng.set_option("gemm_variant", v)

@@ -179,7 +179,8 @@ def test_fused_qkv_attention_launch_is_bitwise_the_two_launches(eng):
 
 def test_fused_launches_fall_back_when_the_device_is_shared(eng):
     """The fused launches spin on granules written by other blocks of their grid: they need all 256 blocks resident.  Another
-    stream that holds most CUs (here: 250 workgroups with 160 KiB of LDS each, for 0.4 s) breaks that.  The engine must notice (one
+    stream that holds most CUs (here: 224 workgroups with 160 KiB of LDS each = 224 whole CUs, until the test lets go; at most 2 s)
+    breaks that: the 32 CUs that are left cannot hold 256 blocks of 256 threads at these kernels' register budgets.  The engine must notice (one
     bounded 20 ms sweep, then every other sweep gives up at once), switch to the five-launch chain -- which needs no co-residency
     and produces the same bits -- run the generation again and return the SAME tokens, not MA_ERR_HIP."""
     if eng.get_option("chain_resident") != 1:
@@ -188,13 +189,21 @@ def test_fused_launches_fall_back_when_the_device_is_shared(eng):
     want, want_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
     want = want.cpu()
     base = eng.get_option("chain_fallbacks")
+    import time
     side = torch.cuda.Stream()
+    release = torch.zeros(1, dtype=torch.int32).pin_memory()
     torch.cuda.synchronize()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record()
-    eng.occupy_cus(250, 400_000, stream=side)                      # 250 of the 256 CUs are gone for 0.4 s
-    got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
-    t1.record(); torch.cuda.synchronize()
+    t0 = time.time()
+    # 224 of the 256 CUs are gone until `release` is set: the prefill runs on the 32 that are left (1/8 of the chip), the first fused decode
+    # launch then cannot get its 256 blocks resident.  (Measured, profiles/r03_diag_stream_concurrency.txt: a 128-CU hog changes nothing --
+    # 256 blocks still fit; a 250-CU hog starves every kernel of the other stream until it ends.)
+    eng.occupy_cus(224, 2_000_000, stream=side, release=release)
+    try:
+        got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
+    finally:
+        release[0] = 1
+    t1 = time.time()
+    torch.cuda.synchronize()
     try:
         assert eng.get_option("chain_fallbacks") == base + 1, "the starved grid was not noticed"
         assert eng.get_option("chain_resident") == 0 and eng.get_option("fuse_qkv_attn") == 0 and eng.get_option("fuse_oproj_fc1") == 0
@@ -202,7 +211,7 @@ def test_fused_launches_fall_back_when_the_device_is_shared(eng):
         # the engine stays on the five-launch chain (no spinning on a device that has shown to be shared): still the same tokens
         again, _ = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
         assert torch.equal(again.cpu(), want)
-        print(f"[fallback] starved generation of {n} tokens took {t0.elapsed_time(t1):.0f} ms incl. one 20 ms bounded sweep and the re-run")
+        print(f"[fallback] starved generation of {n} tokens took {1e3 * (t1 - t0):.0f} ms on 32 CUs, incl. one 20 ms bounded sweep and the re-run")
     finally:
         side.synchronize()
         eng.set_option("chain_resident", 1)                          # re-arm for the tests that follow

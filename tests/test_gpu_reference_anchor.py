@@ -8,7 +8,7 @@ code (tests/golden/make_golden.py, committed fixtures; nothing here reads /root/
     ShapeOPTDecoder.forward trace, within a stated bound, and the same token wherever the reference's top-1/top-2 margin exceeds
     twice that bound; the detokenizer's bins against NoiseResistantDecoder.forward's wherever ITS margin exceeds the bound.
 Bounds (max abs logit error against the fp32 reference): fp32 policy 2e-3; bf16 policy 6e-2 for the decoder (24 layers of bf16 GEMV
-inputs) and 8e-2 for the detokenizer logits."""
+inputs) and 2.5e-2 for the detokenizer logits (measured: 0.036 and 0.015, profiles/r03_reference_anchor.txt)."""
 import os
 
 import numpy as np
@@ -109,7 +109,7 @@ def test_350m_logits_and_bins_against_the_reference_modules(policy, golden_dir):
     bins = torch.round((coords[0].reshape(-1, 9) + 0.5) * cfg.discrete_num).long()           # undiscretize^-1 (meshanything.py:214-223)
     ref_bins = torch.from_numpy(a["anchor_detok_bins"]).long()
     margin = torch.from_numpy(a["anchor_detok_margin"])
-    dbound = {"fp32": 2e-3, "bf16": 8e-2}[policy]
+    dbound = {"fp32": 2e-3, "bf16": 2.5e-2}[policy]
     diff = (bins != ref_bins) & valid[:, None]
     n_valid = int(valid.sum()) * 9
     print(f"[{policy}] 350M detokenizer vs the reference's NoiseResistantDecoder.forward: {int(diff.sum())} of {n_valid} bins differ; "
