@@ -32,6 +32,7 @@
 #include "oproj_fc1.hpp"
 #include "persist.hpp"
 #include "qkv_attn.hpp"
+#include "rows_fused.hpp"
 #include "layer_fused.hpp"
 #include "state.hpp"
 #include "weights.hpp"
@@ -126,6 +127,11 @@ struct ma_engine {
     bf16_t* a_vt = nullptr; size_t vt_elems = 0;      // its V^T workspace
     int opt_attn_rowwave = 1;        // MFMA decode path below that: one wave per (row, head, chunk) (1) or one block (0)
     // persistent decode step (persist.hpp): batch 1, bf16, greedy, 350M-shaped layers on a 256-CU device
+    int opt_rows_fused = 0;          // 2 .. 8 rows: the two-launch layer with the rows looped inside the 256 blocks (rows_fused.hpp).  Opt-in: bit-identical
+                                     // to batch-1 runs, 51 launches per step, but 1.4-1.9x SLOWER than the matrix-core chain (profiles/r03_rows_fused_*)
+    int opt_rows_fused_min = 4;      // smallest batch that takes it (below: the batch-1 fused launches with the rows in the grid)
+    bool rf_ok = false;              // its second launch (130 KB of LDS) can be resident on every CU of this device
+    u64* d_part_gran = nullptr;      // [max_batch][heads][16][66] granules: its in-launch split-KV partial exchange
     int opt_qkv_xcd_local = 1;       // fused q/k/v + attention launch: the 16 blocks of a head on one XCD (qkv_attn.hpp qkv_block_role)
     int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
@@ -599,6 +605,36 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     }
 }
 
+// 2 .. 8 rows on the rows-looped two-launch layer: 256 blocks whatever the batch, so the residency condition is the batch-1 one
+bool use_rows_fused(ma_engine* e, int B, int len_override) {
+    const ma_config& c = e->cfg;
+    return e->opt_rows_fused && e->rf_ok && e->chain_resident && len_override < 0 && e->bf16 && B >= std::max(2, e->opt_rows_fused_min) && B <= RF_MAX_ROWS &&
+           c.hidden == 1024 && c.ffn == 4096 && c.heads * 64 == c.hidden && c.heads * ATTN_NCHUNK == 256 && c.layers <= 30;
+}
+
+void enqueue_layer_rows_fused(ma_engine* e, hipStream_t s, int l, const float* x_in, const float* ln_g, const float* ln_b, StepTimer& tm, Rows rw) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden;
+    const size_t r0 = rw.r0;
+    RowsFusedArgs A{};
+    A.q = make_qkv_attn_args(e, l, x_in, ln_g, ln_b, -1, rw);
+    A.q.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
+    const float* resid = ln_g ? e->d_h0 + r0 * H : x_in;
+    A.o = make_oproj_fc1_args(e, l, resid, rw, true);
+    A.o.trace = tm.trace_slot(3, H / 4);
+    A.part_gran = e->d_part_gran + r0 * c.heads * ATTN_NCHUNK * RF_PART;
+    A.attn_out = e->d_xb + r0 * H; A.attn_out_stride = H;
+    A.B = rw.B;
+    if (tm.on(1)) {
+        hipError_t r = launch_qkv_attn_rows(A, c.heads, s);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("qkv_attn_rows launch failed: ") + hipGetErrorString(r));
+    }
+    if (tm.on(0)) {
+        hipError_t r = launch_oproj_fc1_rows(A, H, c.ffn, s);
+        if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("oproj_fc1_rows launch failed: ") + hipGetErrorString(r));
+    }
+}
+
 bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
 
 // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp); belongs to the "cache" class of the profiler
@@ -626,7 +662,7 @@ void enqueue_lm_head(ma_engine* e, hipStream_t s, const float* x, int x_stride, 
 void enqueue_pick(ma_engine* e, hipStream_t s, StepTimer& tm, Rows rw) {
     if (!tm.on(3)) return;
     hipLaunchKernelGGL(pick_kernel, dim3(rw.B), dim3(256), (size_t)e->V * sizeof(float), s, e->d_logits + (size_t)rw.r0 * e->V, e->V,
-                       e->d_pval + (size_t)rw.r0 * e->V, e->d_pidx + (size_t)rw.r0 * e->V, use_mfma_decode(e, rw.B) ? 0 : e->n_parts, e->V, e->d_st + rw.r0,
+                       e->d_pval + (size_t)rw.r0 * e->V, e->d_pidx + (size_t)rw.r0 * e->V, (use_mfma_decode(e, rw.B) && !use_rows_fused(e, rw.B, -1)) ? 0 : e->n_parts, e->V, e->d_st + rw.r0,
                        e->w_tokens + (size_t)rw.r0 * e->maxnew, e->maxnew, e->T);
     HIP_CHECK(hipGetLastError());
 }
@@ -708,7 +744,14 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, rw.B);
     }
-    if (use_mfma_decode(e, rw.B)) {
+    if (use_rows_fused(e, rw.B, len_override)) {
+        const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
+        for (int l = 0; l < c.layers; ++l) {
+            if (l == 0) enqueue_layer_rows_fused(e, s, 0, de, nullptr, nullptr, tm, rw);
+            else enqueue_layer_rows_fused(e, s, l, y2, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, tm, rw);
+        }
+        enqueue_lm_head(e, s, y2, H, e->dl[c.layers - 1].ln2_g, e->dl[c.layers - 1].ln2_b, tm, rw);
+    } else if (use_mfma_decode(e, rw.B)) {
         enqueue_layers_mfma(e, s, de, len_override, tm, rw);
     } else {
         const float* y2 = e->d_ypre2 + (size_t)rw.r0 * H;
@@ -828,6 +871,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipMemsetAsync(e->d_ffn_gran, 0, (size_t)e->cfg.max_batch * e->cfg.ffn * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_attn_pair_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_PAIR_GRANULES * sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(e->d_y2_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_part_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_NCHUNK * RF_PART * sizeof(u64), s));
 }
 
 ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
@@ -1020,6 +1064,8 @@ void build_engine(ma_engine* e) {
     HIP_CHECK(hipMemset(e->d_y2_gran, 0, MB * H * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
     HIP_CHECK(hipMemset(e->d_ffn_gran, 0, MB * (size_t)c.ffn * sizeof(u64)));
+    e->d_part_gran = e->dmalloc<u64>(MB * (size_t)c.heads * ATTN_NCHUNK * RF_PART);
+    HIP_CHECK(hipMemset(e->d_part_gran, 0, MB * (size_t)c.heads * ATTN_NCHUNK * RF_PART * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_chain_err, 0, sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
@@ -1041,6 +1087,12 @@ void build_engine(ma_engine* e) {
             const int usable = occ_min > 1 ? occ_min - 1 : occ_min;              // blocks per CU counted on
             e->resident_blocks = (long)e->n_cus * usable;
             e->chain_resident = e->resident_blocks * 4 >= 256L * 5;
+            // the rows-looped launches: the second one holds 66-130 KB of LDS, i.e. ONE block per CU -- an LDS bound, where the occupancy
+            // query is exact (its off-by-one concerns the SGPR-limited high-occupancy cases): 256 blocks need 256 CUs
+            int occ_r = 0;
+            e->rf_ok = e->bf16 && rf_prepare() == hipSuccess &&
+                       hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_r, oproj_fc1_rows_kernel<8>, 256, rf_oproj_lds(8)) == hipSuccess && (long)e->n_cus * occ_r >= 256;
+            if (!e->rf_ok) (void)hipGetLastError();
         }
         e->persist_shape = e->bf16 && c.hidden == PS_H && c.ffn == PS_F && c.heads == PS_HEADS && c.codebook_dim == PS_H && c.heads * ATTN_NCHUNK == PS_CUS &&
                            e->V >= PS_CUS * 32 && e->V <= PS_CUS * 33 && e->n_cus == PS_CUS && (size_t)prop.sharedMemPerBlockOptin >= PL_TOTAL;
@@ -1192,6 +1244,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
         else if (n == "fuse_fc2") { e->opt_fuse_fc2 = (int)value; drop_graphs(e); }
         else if (n == "qkv_xcd_local") { e->opt_qkv_xcd_local = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "rows_fused") { e->opt_rows_fused = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "rows_fused_min") { e->opt_rows_fused_min = (int)value; drop_graphs(e); }
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
@@ -1245,6 +1299,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
         else if (n == "fuse_fc2") *value = e->opt_fuse_fc2;
         else if (n == "qkv_xcd_local") *value = e->opt_qkv_xcd_local;
+        else if (n == "rows_fused") *value = e->opt_rows_fused && e->rf_ok && e->chain_resident ? 1 : 0;
+        else if (n == "rows_fused_min") *value = e->opt_rows_fused_min;
         else if (n == "fuse_layer") *value = fuse_layer(e) ? 1 : 0;
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
@@ -1804,8 +1860,9 @@ int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launch
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         ma_sample_cfg sc = resolve_sample_cfg(e, nullptr);
         sc.suppress_eos = 1;
-        init_state(e, s, sc, 1, e->maxnew);
-        hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5, 1);
+        const int TB = std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch));      // rows of the traced step (option profile_batch)
+        init_state(e, s, sc, TB, e->maxnew);
+        hipLaunchKernelGGL(set_pos_kernel, dim3(ceil_div(TB, 64)), dim3(64), 0, s, e->d_st, kv_len - e->T, kv_len - 1, 5, TB);
         HIP_CHECK(hipGetLastError());
         const size_t n64 = (size_t)max_launches * max_blocks * 4;
         unsigned long long* d_tr = nullptr;
@@ -1813,10 +1870,10 @@ int ma_trace_decode(ma_engine* e, int kv_len, uint64_t* host_out, int max_launch
         try {
             HIP_CHECK(hipMemsetAsync(d_tr, 0, n64 * sizeof(unsigned long long), s));
             StepTimer none;
-            for (int i = 0; i < 3; ++i) enqueue_decode_step(e, s, -1, none);            // warm: clocks, caches
+            for (int i = 0; i < 3; ++i) enqueue_decode_step(e, s, -1, none, Rows{0, TB});            // warm: clocks, caches
             std::vector<int> k, b;
             StepTimer tm; tm.tr = d_tr; tm.tr_max_launches = max_launches; tm.tr_max_blocks = max_blocks; tm.tr_kind = &k; tm.tr_blocks = &b;
-            enqueue_decode_step(e, s, -1, tm);
+            enqueue_decode_step(e, s, -1, tm, Rows{0, TB});
             HIP_CHECK(hipMemcpyAsync(host_out, d_tr, n64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             *n_launches = (int)k.size();

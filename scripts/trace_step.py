@@ -11,13 +11,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--lens", default="300,3800,7400")
 ap.add_argument("--options", default="")
+ap.add_argument("--batch", type=int, default=1)
 a = ap.parse_args()
-cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32)
+cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, max_batch=a.batch)
 eng = Engine(cfg)
 eng.load_weights(synthetic_items(cfg))
 for kv in a.options.split(","):
     if kv:
         k, v = kv.split("="); eng.set_option(k, int(v))
+eng.set_option("profile_batch", a.batch)
 names = ["embed", "qkv", "attn", "oproj", "fc1", "fc2", "lmhead"]
 for L in [int(x) for x in a.lens.split(",")]:
     t = eng.trace_decode(L)

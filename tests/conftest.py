@@ -77,6 +77,7 @@ _ORDER = (
     ("test_gpu_pipeline.py", "test_large_batches"),
     ("test_gpu_pipeline.py", "test_weights_"),
     ("test_gpu_persist.py", ""),
+    ("test_gpu_rows_fused.py", ""),
     ("test_gpu_reference_anchor.py", ""),
     ("test_gpu_pipeline.py", "[bf16]"),
     ("test_gpu_pipeline.py", "test_v2_scale"),
