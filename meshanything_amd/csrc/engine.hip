@@ -64,6 +64,35 @@ struct ChainTimeout : MaError {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// roctx ranges around the phases of the hot path (tracing): resolved lazily from libroctx64.so, active only when
+// MA_ROCTX=1 is set in the environment (rocprofv3 --marker-trace then shows encode / prefill / decode / detokenize as ranges)
+struct RoctxRange {
+    typedef int (*push_fn)(const char*);
+    typedef int (*pop_fn)();
+    static push_fn& push() { static push_fn f = nullptr; return f; }
+    static pop_fn& pop() { static pop_fn f = nullptr; return f; }
+    static bool enabled() {
+        static int state = -1;
+        if (state < 0) {
+            state = 0;
+            const char* v = getenv("MA_ROCTX");
+            if (v && v[0] == '1') {
+                void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+                if (h) {
+                    push() = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+                    pop() = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+                    state = push() && pop() ? 1 : 0;
+                }
+            }
+        }
+        return state == 1;
+    }
+    bool on;
+    explicit RoctxRange(const char* name) : on(enabled()) { if (on) push()(name); }
+    ~RoctxRange() { if (on) pop()(); }
+};
+
 }  // namespace
 
 struct ma_engine {
@@ -905,10 +934,14 @@ int generate_batch_once(ma_engine* e, hipStream_t s, const float* prefix, int B,
     ensure_graph(e, B, impl);
     init_state(e, s, sc, B, maxn);
     // prefill in groups of rows (bounded workspace: prefill_rows samples at a time)
-    for (int b0 = 0; b0 < B; b0 += e->prefill_rows) {
-        const int nb = std::min(e->prefill_rows, B - b0);
-        prefill(e, s, prefix + (size_t)b0 * e->T * e->cfg.hidden, b0, nb);
+    {
+        RoctxRange range("ma_generate: prefill");
+        for (int b0 = 0; b0 < B; b0 += e->prefill_rows) {
+            const int nb = std::min(e->prefill_rows, B - b0);
+            prefill(e, s, prefix + (size_t)b0 * e->T * e->cfg.hidden, b0, nb);
+        }
     }
+    RoctxRange range_decode("ma_generate: decode steps");
     if (e->opt_prefill_stepwise) init_state(e, s, sc, B, maxn);         // the stepwise prefill used the state's pos field
     StepTimer none;
     enqueue_pick(e, s, none, Rows{0, B});                                // token 0 (expected bos; dropped later, meshanything.py:166)
@@ -1470,6 +1503,7 @@ int ma_encode(ma_engine* e, const void* pc, int pc_dtype, int B, float* latents,
         require_ready(e); check_batch(e, B);
         if (pc_dtype != MA_DTYPE_F32 && pc_dtype != MA_DTYPE_F16) throw MaError(MA_ERR_INVALID, "pc_dtype must be F32 or F16");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        RoctxRange range("ma_encode");
         const size_t pstride = (size_t)e->cfg.n_points * 6 * (pc_dtype == MA_DTYPE_F16 ? 2 : 4);
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {          // the whole chunk goes through every GEMM at once (M = nb x rows)
             const int nb = std::min(e->dense_rows, B - b0);
@@ -1553,6 +1587,7 @@ int ma_detokenize_embeds(ma_engine* e, const int64_t* ids, const float* codes, c
     return guarded(e, [&] {
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        RoctxRange range("ma_detokenize");
         const size_t nf = e->nf;
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
             const int nb = std::min(e->dense_rows, B - b0);

@@ -57,16 +57,19 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_
 // form keeps the younger tiles flying across the barrier; what it must still order is covered explicitly: this wave's own pieces of
 // tile kt by the counted vmcnt, everyone's by the barrier behind it, and the stage that is re-filled was read one iteration earlier
 // (its ds_reads retired by the lgkmcnt(0) in front of this barrier).
-template <int BM, int BN, int BK, int NS, bool RAW = false>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
+// WM x WN waves (default 2 x 2): each wave a (BM / WM) x (BN / WN) sub-tile.  The 4 x 2 form carries a 256 x 128 block tile on 8 waves: a
+// third less LDS fill per FLOP than 128 x 128 (the loop is bound by the LDS-DMA issue and fill rate, not by the matrix cores).
+template <int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
+    constexpr int NW = WM * WN;
     constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
     auto swz = [](int r) { return CH == 8 ? (r & 7) : ((r >> 1) & 3); };
     constexpr int RPI = 64 / CH;                      // tile rows one DMA instruction covers
     constexpr int ROWB = BK * 2;                      // bytes per tile row
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
-    constexpr int TM = BM / 32, TN = BN / 32;         // 16 x 16 MFMA tiles per wave along m / n
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;   // 16 x 16 MFMA tiles per wave along m / n
     extern __shared__ __attribute__((aligned(16))) char gt_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WN, wn = w % WN;
     // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own L2.  With the plain
     // (x = N tile, y = M tile) order and 8 N tiles, XCD i would own N-tile column i and stream EVERY activation tile through
     // its L2: 8 x the activation bytes over the fabric.  Remapped, XCD i owns the i-th eighth of the tile list in (m, n)
@@ -89,14 +92,14 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
         const int k0 = kt * BK;
         const unsigned sbase = lds0 + (unsigned)stage * STAGE;
 #pragma unroll
-        for (int p = w; p < BM / RPI; p += 4) {
+        for (int p = w; p < BM / RPI; p += NW) {
             const int r = p * RPI + drow;
             const int m = min(bm + r, g.M - 1);
             const bf16_t* src = g.A + (size_t)m * g.lda + k0 + ((dslot ^ swz(r)) * 8);
             gt_glds16(src, __builtin_amdgcn_readfirstlane(sbase + (unsigned)p * 1024u));
         }
 #pragma unroll
-        for (int p = w; p < BN / RPI; p += 4) {
+        for (int p = w; p < BN / RPI; p += NW) {
             const int r = p * RPI + drow;
             const int n = min(bn + r, g.N - 1);
             const bf16_t* src = g.W + (size_t)n * g.K + k0 + ((dslot ^ swz(r)) * 8);
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     const int fr = lane & 15, kg = lane >> 4;          // fragment row, 8-element k group
     const int nk = g.K / BK;
     constexpr int PF = NS - 1;                         // K-tiles in flight ahead of the one being multiplied
-    constexpr int IPW = (BM / RPI + BN / RPI) / 4;     // DMA instructions per wave and K-tile
-    static_assert((BM / RPI) % 4 == 0 && (BN / RPI) % 4 == 0 && (PF - 1) * IPW < 64, "tile shape");
+    constexpr int IPW = (BM / RPI + BN / RPI) / NW;    // DMA instructions per wave and K-tile
+    static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0 && (PF - 1) * IPW < 64, "tile shape");
 #pragma unroll
     for (int t = 0; t < PF; ++t) if (t < nk) issue(t, t);
     int stage = 0;
@@ -131,12 +134,12 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
             bf16x8_t wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const int r = wn * (BN / 2) + i * 16 + fr;
+                const int r = wn * (BN / WN) + i * 16 + fr;
                 wf[i] = *reinterpret_cast<const bf16x8_t*>(sw + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int r = wm * (BM / 2) + j * 16 + fr;
+                const int r = wm * (BM / WM) + j * 16 + fr;
                 xf[j] = *reinterpret_cast<const bf16x8_t*>(sa + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
     // ---- epilogue: lane holds n = n0 .. n0 + 3 of row m ------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const int n0 = bn + wn * (BN / 2) + i * 16 + kg * 4;
+        const int n0 = bn + wn * (BN / WN) + i * 16 + kg * 4;
         if (n0 >= g.N) continue;
         const bool full = n0 + 3 < g.N;
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
         }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            const int m = bm + wm * (BM / 2) + j * 16 + fr;
+            const int m = bm + wm * (BM / WM) + j * 16 + fr;
             if (m >= g.M) continue;
             const size_t mr = (size_t)(g.r_mod > 0 ? m % g.r_mod : m), mo = g.cmap(m);
             f32x4 v = acc[i][j];
@@ -194,16 +197,16 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmTArgs g) {
 // 2 stages, raw barrier (default) | 7 = K-tile 32, 6 stages, raw barrier | 8 = the 128 x 64 tile for every shape (A/B of the tail rounds)
 inline int& gemm_tile_variant() { static int v = 6; return v; }      // 6: +2 ... +13 % over 0 on the path's shapes (profiles/r03_ab_dense_attention_gemm_variants.txt)
 
-template <int BM, int BN, int BK, int NS, bool RAW = false>
+template <int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
 inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static bool attr = false;
     if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW>), dim3((g.N + BN - 1) / BN, (g.M - g.m_begin + BM - 1) / BM), dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M - g.m_begin + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
     return hipGetLastError();
 }
 
@@ -214,6 +217,9 @@ inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
     const int v = gemm_tile_variant();
     if (v == 8 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 2, true>(g, s);      // A/B: the half tile everywhere
+    if (v == 12 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 64, 2, true, 4, 2>(g, s);    // A/B: 256 x 128 tile, 8 waves, 96 KB
+    if (v == 13 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 64, 3, true, 4, 2>(g, s);    // A/B: ... three stages, 144 KB
+    if (v == 14 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 32, 4, true, 4, 2>(g, s);    // A/B: ... K-tile 32, four stages, 96 KB
     if (v == 9 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 3, true>(g, s);     // A/B: 48 KB of LDS: three blocks per CU
     if (v == 10 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 3, true>(g, s);     // A/B: half tile, two K-tiles in flight
     if (v == 11 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 2, true>(g, s);    // A/B: 32 KB of LDS: four-five blocks per CU

@@ -14,8 +14,11 @@ algorithm; where the container holds a newer copy the restatement cites it.
 PIN STATUS: every function the reference's own code can execute here is pinned against that code's output (below); the
 `generate()` loop semantics are pinned against the container's HuggingFace `GenerationMixin.generate` driving this
 oracle's step function (tests/test_generate_loop_vs_hf.py); the reference's own ShapeOPTDecoder.forward is pinned through
-tests/golden/shapeopt_forward.npz (prefix call + cached steps).  PARITY UNPINNED: only the outermost composition, the
-ShapeOPT CausalLM wrapper under transformers==4.39.3 generate() with flash-attn (cannot be constructed in this container).
+tests/golden/shapeopt_forward.npz (prefix call + cached steps); the OUTERMOST composition -- the reference's ShapeOPT CausalLM
+wrapper under the container's GenerationMixin.generate with the call of meshanything.py:143-151 -- through
+tests/golden/shapeopt_generate.npz (tests/test_reference_anchor.py; three documented version shims, none in the arithmetic); the
+350M-shape logits and detokenizer bins through tests/golden/full_anchor.npz.  Outside the pins: transformers==4.39.3 itself and
+flash-attn (absent from this container; eager attention behind a 4.39.3-signature adapter).
 
 How it is pinned: the reference has no tests and no golden vectors, so the oracle
 is pinned against outputs of the reference's *own code* run in the authoring container
@@ -24,9 +27,8 @@ is pinned against outputs of the reference's *own code* run in the authoring con
 `encode_latents`, `to_shape_latents`, `process_point_feature`, `embed_with_vae`,
 `OPTFacePositionalEmbedding`, `get_codes`, `NoiseResistantDecoder.forward`, `undiscretize`;
 and against the container's transformers copy: `OPTLearnedPositionalEmbedding`, `OPTDecoderLayer`
-(post-LN) stack with KV cache, BERT layer, TopK/TopP warpers.  NOT pinnable (the reference cannot run
-it here: flash-attn + hub downloads): the `generate()` loop as a whole -- it is restated
-(`generate`) from those pinned pieces.
+(post-LN) stack with KV cache, BERT layer, TopK/TopP warpers; `generate` as a whole against the reference's ShapeOPT wrapper
+under GenerationMixin.generate (above).
 
 Device (`device`): "cpu" (default; what the CPU suite, the golden pins and bench.py's cpu_baseline use) or a torch-ROCm device.
   On "cuda" the SAME statements below run as stock PyTorch fp32 ops (rocBLAS GEMMs with TF32-style shortcuts disabled, eager

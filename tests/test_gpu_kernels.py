@@ -468,7 +468,7 @@ def test_rows_prologue(lib, B, pro):
                                                    (4112, 1024, 4096, 0, True, "f32"), (2056, 768, 768, 2, False, "both"), (65536, 1536, 768, 0, False, "bf16"),
                                                    (257, 2304, 768, 0, False, "bf16"), (130, 200, 192, 0, True, "both"), (1, 1024, 768, 0, False, "f32"),
                                                    (16912, 768, 3072, 0, True, "f32"), (300, 64, 768, 0, False, "f32"), (77, 1152, 96, 0, False, "f32")])
-@pytest.mark.parametrize("variant", [0, 6], ids=["syncthreads", "rawbarrier"])
+@pytest.mark.parametrize("variant", [0, 6, 12, 13], ids=["syncthreads", "rawbarrier", "tile256x128", "tile256x128s3"])
 def test_gemm_bf16_tile(lib, M, N, K, act, use_res, out, variant):
     """The bf16 policy's dense GEMM (gemm_tile.hpp) on its native bf16 operands at the batched dense-phase shapes (B x 257,
     B x 4096, B x 1057 rows), ragged edges, both tile variants; fp32 and bf16 outputs; reports TFLOP/s.  variant: the K-loop's
