@@ -223,10 +223,12 @@ inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     if (v == 9 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 3, true>(g, s);     // A/B: 48 KB of LDS: three blocks per CU
     if (v == 10 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 3, true>(g, s);     // A/B: half tile, two K-tiles in flight
     if (v == 11 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 2, true>(g, s);    // A/B: 32 KB of LDS: four-five blocks per CU
-    // OPT-prefill shapes (K = hidden | ffn, N >= hidden, M = B x 257): the 32 KB-of-LDS form (K-tile 32, four to five blocks per CU) hides the
-    // per-tile latency better than two 64 KB blocks: 60 vs 70 us (N = K = 1024), 205 vs 262 us (N = 4096), 178 vs 190 us (K = 4096) at M = 16448
-    // (profiles/r03_ab_gemm_tile_occupancy_and_tail.txt); K = 768 shapes and very tall problems prefer the 64 KB form
-    if (v == 6 && g.K % 64 == 0 && g.K >= 1024 && g.N >= 1024 && g.M > 64 && g.M <= 32768 && tiles128 >= 160) return gt_launch<128, 128, 32, 2, true>(g, s);
+    // Problems with many tiles (the detokenizer's M = B x 1057, wide N): the 256 x 128 tile on 8 waves with three LDS stages (144 KB, one block
+    // per CU) -- a third less LDS fill per FLOP.  Isolated: 569 vs 504 TFLOP/s (67648 x 3072 x 768), 602 vs 514 (262144 x 1536 x 768), 983 vs
+    // 720-868 on 8192^3 (profiles/r03_ab_gemm_tile_occupancy_and_tail.txt); inside the pipeline the detokenizer gains 2.6 %, the encoder's
+    // 262144-row GEMM loses (profiles/r03_ab_dense_gemm_selection_in_pipeline.txt), so it is kept to 2048 .. 16384 tiles of M <= 131072.  The
+    // higher-occupancy K-tile-32 form that wins 10-20 % in isolation on the OPT-prefill shapes measures no gain in the pipeline: not used.
+    if (v == 6 && g.K % 64 == 0 && g.M > 128 && g.M <= 131072 && g.N > 64 && tiles128 >= 2048) return gt_launch<256, 128, 64, 3, true, 4, 2>(g, s);
     if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) {
         if (v == 1) return gt_launch<128, 128, 32, 4>(g, s);
         if (v == 2) return gt_launch<128, 128, 32, 5>(g, s);

@@ -8,6 +8,7 @@
 usage: pmc_r2_report.py decode_raw.json dense_raw.json outdir"""
 import json, os, sys
 dec, den, out = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3]
+RND = sys.argv[4] if len(sys.argv) > 4 else "r02"
 
 def cls(name):
     if "qkv_attn_kernel" in name or "attn_decode_kernel" in name:
@@ -32,7 +33,7 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
        "hbm_bytes_per_launch": {c: int(v[0] / max(1, v[1])) for c, v in acc.items()},
        "dispatches": {c: v[1] for c, v in acc.items()}, "per_kernel": per_kernel,
        "note": "the 'cache' class mixes cache lengths 257..~450 of the profiled run: compare with algorithmic bytes at that length, not at mid context"}
-json.dump(res, open(os.path.join(out, "r02_pmc_decode_traffic.json"), "w"), indent=1, sort_keys=True)
+json.dump(res, open(os.path.join(out, RND + "_pmc_decode_traffic.json"), "w"), indent=1, sort_keys=True)
 
 rows = {}
 for k, cs in den.items():
@@ -44,8 +45,8 @@ for k, cs in den.items():
     rows[k] = {"dispatches": mf["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": round(mf["mean"], 1), "GRBM_GUI_ACTIVE": round(ga["mean"], 1),
                "mfma_busy_frac": round(mf["mean"] / (ga["mean"] / 8.0 * 1024), 4)}
 tot_m = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["dispatches"] for v in rows.values())
-tot_all = sum(cs["GRBM_GUI_ACTIVE"]["mean"] * cs["GRBM_GUI_ACTIVE"]["dispatches"] for k, cs in den.items() if "GRBM_GUI_ACTIVE" in cs and any(t in k for t in ("gemm_tile", "attention_mfma", "ln_rows2", "kv_fill2", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")))
+tot_all = sum(cs["GRBM_GUI_ACTIVE"]["mean"] * cs["GRBM_GUI_ACTIVE"]["dispatches"] for k, cs in den.items() if "GRBM_GUI_ACTIVE" in cs and any(t in k for t in ("gemm_tile", "attention_mfma", "vt_pack", "ln_rows2", "kv_fill2", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")))
 json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace on scripts/prof_dense.py --batches 64 --iters 1",
            "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); dense_phase = MFMA cycles of all kernels / active cycles of all dense-phase kernels (GEMM, attention, LayerNorm, gathers)",
            "dense_phase_mfma_busy_frac": round(tot_m / max(1.0, tot_all / 8.0 * 1024), 4), "per_kernel": rows},
-          open(os.path.join(out, "r02_pmc_dense_mfma.json"), "w"), indent=1, sort_keys=True)
+          open(os.path.join(out, RND + "_pmc_dense_mfma.json"), "w"), indent=1, sort_keys=True)

@@ -472,7 +472,8 @@ def test_rows_prologue(lib, B, pro):
 def test_gemm_bf16_tile(lib, M, N, K, act, use_res, out, variant):
     """The bf16 policy's dense GEMM (gemm_tile.hpp) on its native bf16 operands at the batched dense-phase shapes (B x 257,
     B x 4096, B x 1057 rows), ragged edges, both tile variants; fp32 and bf16 outputs; reports TFLOP/s.  variant: the K-loop's
-    barrier form (engine option gemm_variant: 0 = __syncthreads(), 6 = counted vmcnt + raw s_barrier, the default)."""
+    barrier form and tile (engine option gemm_variant: 0 = __syncthreads(), 6 = counted vmcnt + raw s_barrier with the per-shape tile choice
+    of launch_gemm_tile, the default; 12 / 13 = the 8-wave 256 x 128 tile with two / three LDS stages everywhere)."""
     from meshanything_amd.config import MAConfig, DTYPE_BF16
     from meshanything_amd.engine import Engine
     knob = Engine(MAConfig.tiny(dtype=DTYPE_BF16))                      # gemm_variant is a process-wide knob behind an engine option
