@@ -6,9 +6,9 @@
 
 Same flags as the reference.  Differences, all forced by the environment (no network, no trimesh): the checkpoint is
 read from `--pretrained_weights` (the reference ignores that flag and downloads `MeshAnything_350m.pth`, main.py:95-98;
-`--synthetic_weights` uses the seeded random checkpoint of the tests instead), `--input_type mesh` is not available
-(needs trimesh / mesh2sdf surface sampling); the mesh clean-up of main.py:156-175 is restated without trimesh in
-`meshanything_amd/mesh_export.py`.
+`--synthetic_weights` uses the seeded random checkpoint of the tests instead); `--input_type mesh` reads .obj / .ply / .off /
+.stl and samples the surface in numpy (`meshanything_amd/mesh_input.py`), `--mc` is refused (needs mesh2sdf + scikit-image); the
+mesh clean-up of main.py:156-175 is restated without trimesh in `meshanything_amd/mesh_export.py`.
 Multi-GPU: one process per GPU; rank r takes the shapes i % world == r and the weights travel in one RCCL broadcast.
 """
 import argparse
@@ -62,7 +62,10 @@ def main():
 
     if args.input_dir is not None:
         input_list = sorted(os.listdir(args.input_dir))
-        input_list = [os.path.join(args.input_dir, x) for x in input_list if x.endswith(".npy")]
+        if args.input_type == "pc_normal":
+            input_list = [os.path.join(args.input_dir, x) for x in input_list if x.endswith(".npy")]
+        else:                                    # main.py:125-128 keeps .ply / .obj / .npy for meshes; .npy is not a mesh file, .off / .stl are read too
+            input_list = [os.path.join(args.input_dir, x) for x in input_list if x.lower().endswith((".ply", ".obj", ".off", ".stl"))]
     elif args.input_path is not None:
         input_list = [args.input_path]
     else:

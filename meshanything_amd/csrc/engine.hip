@@ -124,6 +124,9 @@ struct ma_engine {
     std::map<int, hipGraph_t> graph;           // one captured decode step per batch size
     std::map<int, hipGraphExec_t> gexec;
     hipStream_t cap_stream = nullptr;   // capture happens on a private stream (the caller's may be the legacy null stream)
+    // row groups of a batched step (decode_groups): group g steps its rows on grp_stream[g], forked from / joined to the caller's stream
+    int opt_decode_groups = 1;          // 1 = one group (default: measured faster), G = that many (decode_group_count caps it)
+    std::vector<hipStream_t> grp_stream; std::vector<hipEvent_t> grp_done; hipEvent_t grp_fork = nullptr;
 
     // dense-phase workspace: dense_rows samples stacked along the rows.  w_* / p_*: fp32 streams; a_*: activation tensors
     // (dense_ops.hpp: act_elem = 2 bytes under the bf16 policy, 4 under the exact policy)
@@ -428,8 +431,9 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     float* h0 = e->d_h0 + r0 * H; float* q = e->d_q + r0 * H; float* h1 = e->d_h1 + r0 * H; float* y1 = e->d_ypre1 + r0 * H; float* y2 = e->d_ypre2 + r0 * H;
     float* part = e->d_part + r0 * attn_workspace_floats(c.heads);
     bf16_t* xb = e->d_xb + r0 * H; bf16_t* ffb = e->d_ffb + r0 * c.ffn;
-    // split-K partial buffers [ks][B][H]; rows r0.. of a B-row call use the first B rows of each slab (one call at a time)
-    float* partO = e->d_ks_o; float* partF = e->d_ks_f;
+    // split-K partial buffers [ks][B][H] of THIS row range: the ranges of concurrently stepping row groups do not overlap
+    // (4 r0 H floats in front of it belong to the rows before r0, whatever their grouping)
+    float* partO = e->d_ks_o + 4 * r0 * H; float* partF = e->d_ks_f + 4 * r0 * H;
     (void)MB;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     const int ks_o = gemm_dec_ksplit(H, H), ks_f = gemm_dec_ksplit(H, c.ffn);
@@ -806,9 +810,41 @@ void drop_graphs(ma_engine* e) {
     e->gexec.clear(); e->graph.clear();
 }
 
-// one captured step per batch size (the grids depend on B) and step implementation (key = B + 1000 * impl)
-void ensure_graph(ma_engine* e, int B, int impl = 0) {
-    const int key = B + 1000 * impl;
+// ---- row groups ------------------------------------------------------------------------------------------------------------
+// Between 8 and 32 rows the matrix-core chain is bound by the LATENCY of its ~100-150 dependent launches per step (6-7 us each for
+// 1-2 us worth of weight bytes), not by HBM.  The rows of a batch never interact, so the batch can be cut into G row groups that
+// step independently, each on its own HIP stream with its own captured graph, meeting at the end of a burst of steps where the host
+// reads the finished flags.  Group g reproduces an ungrouped run of its rows bit for bit (tests/test_gpu_pipeline.py).
+// MEASURED SLOWER, so opt-in (option decode_groups, default one group): two dependent chains on two hardware queues overlap only about
+// half-way -- 8 rows as 2 x 4: 1522 vs 1290 us per step at kv 3858, 16 rows as 2 x 8: 1921 vs 1803; 3-4 groups: 1.4-2x slower;
+// +2..5 % only at 24-64 rows and long caches (profiles/r03_ab_row_groups.txt).
+int decode_group_count(ma_engine* e, int B, int impl) {
+    if (impl != 0 || !use_mfma_decode(e, B) || use_rows_fused(e, B, -1)) return 1;
+    const int min_rows = std::max(4, e->opt_mfma_min_batch);             // every group stays on the matrix-core path
+    const int G = std::max(1, e->opt_decode_groups);
+    return std::max(1, std::min(G, B / min_rows));
+}
+std::vector<Rows> decode_groups(ma_engine* e, int B, int impl) {
+    const int G = decode_group_count(e, B, impl);
+    std::vector<Rows> g;
+    for (int i = 0, r0 = 0; i < G; ++i) { const int n = B / G + (i < B % G ? 1 : 0); g.push_back(Rows{r0, n}); r0 += n; }
+    return g;
+}
+void ensure_group_streams(ma_engine* e, size_t G) {
+    if (!e->grp_fork) HIP_CHECK(hipEventCreateWithFlags(&e->grp_fork, hipEventDisableTiming));
+    while (e->grp_stream.size() < G) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        e->grp_stream.push_back(st);
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->grp_done.push_back(ev);
+    }
+}
+
+// one captured step per row range (the grids depend on B, the pointers on r0) and step implementation
+int graph_key(Rows rw, int impl) { return rw.B + 1000 * impl + 10000 * rw.r0; }
+void ensure_graph(ma_engine* e, Rows rw, int impl = 0) {
+    const int key = graph_key(rw, impl);
     if (!e->cfg.use_graph || e->gexec.count(key)) return;
     StepTimer none;
     if (!e->cap_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
@@ -816,7 +852,7 @@ void ensure_graph(ma_engine* e, int B, int impl = 0) {
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     try {
-        enqueue_decode_step(e, s, -1, none, Rows{0, B}, impl);
+        enqueue_decode_step(e, s, -1, none, rw, impl);
     } catch (...) {
         (void)hipStreamEndCapture(s, &g);
         if (g) (void)hipGraphDestroy(g);
@@ -828,10 +864,28 @@ void ensure_graph(ma_engine* e, int B, int impl = 0) {
     if (r != hipSuccess) { (void)hipGraphDestroy(g); HIP_CHECK(r); }
     e->graph[key] = g; e->gexec[key] = ge;
 }
+void ensure_graphs(ma_engine* e, int B, int impl = 0) {
+    for (const Rows& rw : decode_groups(e, B, impl)) ensure_graph(e, rw, impl);
+}
 
-void launch_step(ma_engine* e, hipStream_t s, int B, int impl = 0) {
-    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec.at(B + 1000 * impl), s));
-    else { StepTimer none; enqueue_decode_step(e, s, -1, none, Rows{0, B}, impl); }
+void launch_step(ma_engine* e, hipStream_t s, Rows rw, int impl = 0) {
+    if (e->cfg.use_graph) HIP_CHECK(hipGraphLaunch(e->gexec.at(graph_key(rw, impl)), s));
+    else { StepTimer none; enqueue_decode_step(e, s, -1, none, rw, impl); }
+}
+
+// n decode steps of rows 0..B-1, ordered after what is on `s` and before what comes next on it
+void launch_steps(ma_engine* e, hipStream_t s, int B, int impl, int n) {
+    const std::vector<Rows> groups = decode_groups(e, B, impl);
+    if (groups.size() == 1) { for (int i = 0; i < n; ++i) launch_step(e, s, groups[0], impl); return; }
+    ensure_group_streams(e, groups.size());
+    HIP_CHECK(hipEventRecord(e->grp_fork, s));
+    for (size_t g = 0; g < groups.size(); ++g) HIP_CHECK(hipStreamWaitEvent(e->grp_stream[g], e->grp_fork, 0));
+    for (int i = 0; i < n; ++i)
+        for (size_t g = 0; g < groups.size(); ++g) launch_step(e, e->grp_stream[g], groups[g], impl);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        HIP_CHECK(hipEventRecord(e->grp_done[g], e->grp_stream[g]));
+        HIP_CHECK(hipStreamWaitEvent(s, e->grp_done[g], 0));
+    }
 }
 
 // prefill of rows row0 .. row0+B-1 in ONE pass (the samples are stacked along the GEMM rows: M = B * T): ShapeOPTDecoder.forward
@@ -931,7 +985,7 @@ int generate_batch_once(ma_engine* e, hipStream_t s, const float* prefix, int B,
     HIP_CHECK(hipGetLastError());
     const int impl = persist_selected(e, B, sc.do_sample) ? 1 : 0;
     if (impl == 1) ensure_embtab(e, s);
-    ensure_graph(e, B, impl);
+    ensure_graphs(e, B, impl);
     init_state(e, s, sc, B, maxn);
     // prefill in groups of rows (bounded workspace: prefill_rows samples at a time)
     {
@@ -951,7 +1005,7 @@ int generate_batch_once(ma_engine* e, hipStream_t s, const float* prefix, int B,
         // the first burst is ONE step: a grid whose blocks are not all resident (device shared with another stream / process) shows
         // in the error word after the first fused launch, not after 64 steps of zero-filled exchanges
         const int burst = std::min(produced == 1 ? 1 : sc.check_every, maxn - produced);
-        for (int i = 0; i < burst; ++i) launch_step(e, s, B, impl);
+        launch_steps(e, s, B, impl, burst);
         produced += burst;
         HIP_CHECK(hipMemcpyAsync(e->h_state, e->d_st, (size_t)B * sizeof(DecState), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1248,6 +1302,9 @@ void ma_engine_destroy(ma_engine* e) {
     (void)hipSetDevice(e->device);
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (hipStream_t st : e->grp_stream) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : e->grp_done) (void)hipEventDestroy(ev);
+    if (e->grp_fork) (void)hipEventDestroy(e->grp_fork);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->arena) (void)hipFree(e->arena);
     if (e->stage) (void)hipFree(e->stage);
@@ -1272,6 +1329,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_ln") { e->opt_mfma_fold_ln = (int)value; drop_graphs(e); }
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
+        else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
@@ -1327,6 +1385,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else if (n == "mfma_fold_ln") *value = e->opt_mfma_fold_ln;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
+        else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;
         else if (n == "oproj_fc1_sweep_waves") *value = e->opt_oproj_fc1_sweep_waves;
@@ -1834,8 +1893,7 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         const int B = std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch));
         const int impl = persist_selected(e, B, 0) ? 1 : 0;
         if (impl == 1) ensure_embtab(e, s);
-        ensure_graph(e, B, impl);
-        const int gkey = B + 1000 * impl;
+        ensure_graphs(e, B, impl);
         auto reset = [&] {
             init_state(e, s, sc, B, e->maxnew);
             // state as if t tokens had been generated and the cache held kv_len-1 rows
@@ -1851,13 +1909,13 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         auto timed = [&](int only_cls, int* launches) -> float {
             StepTimer tm; tm.only_cls = only_cls;
             reset();
-            if (only_cls == -2) { HIP_CHECK(hipGraphLaunch(e->gexec.at(gkey), s)); }             // warm
+            if (only_cls == -2) launch_steps(e, s, B, impl, 1);                                   // warm
             else { StepTimer w; w.only_cls = only_cls; enqueue_decode_step(e, s, -1, w, Rows{0, B}, impl); }
             reset();
             HIP_CHECK(hipEventRecord(a, s));
-            for (int i = 0; i < steps; ++i) {
-                if (only_cls == -2) HIP_CHECK(hipGraphLaunch(e->gexec.at(gkey), s));
-                else enqueue_decode_step(e, s, -1, tm, Rows{0, B}, impl);
+            if (only_cls == -2) launch_steps(e, s, B, impl, steps);          // what generate() runs: row groups on their streams, joined on s
+            else for (int i = 0; i < steps; ++i) {
+                enqueue_decode_step(e, s, -1, tm, Rows{0, B}, impl);
                 if (only_cls >= 0 && only_cls != 3) {
                     // without the pick launch the state would not advance, and the fused launches tag their in-launch exchanges
                     // with the cache position: move it by hand (one tiny launch per step, charged to the class being timed)

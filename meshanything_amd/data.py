@@ -1,4 +1,4 @@
-"""Input side of the hot path: the reference's `Dataset` (main.py:15-58) for point-cloud inputs."""
+"""Input side of the hot path: the reference's `Dataset` (main.py:15-58) for point-cloud and mesh-file inputs."""
 from __future__ import annotations
 
 import os
@@ -21,7 +21,7 @@ def normalize_pc(pc_normal: np.ndarray) -> np.ndarray:
 
 
 class Dataset:
-    """`Dataset('pc_normal', paths)` of main.py:15-58.  Sampling uses the GLOBAL numpy RNG like the reference
+    """`Dataset('pc_normal' | 'mesh', paths)` of main.py:15-58.  Sampling uses the GLOBAL numpy RNG like the reference
     (seed it first: main.py:129-133 calls accelerate.set_seed(args.seed) -> np.random.seed)."""
 
     def __init__(self, input_type: str, input_list: List[str], mc: bool = False, n_points: int = 4096):
@@ -34,8 +34,14 @@ class Dataset:
                 cur_data = cur_data[idx]
                 self.data.append({"pc_normal": cur_data, "uid": input_path.split("/")[-1].split(".")[0]})
         elif input_type == "mesh":
-            raise NotImplementedError("mesh inputs need surface sampling (trimesh / mesh2sdf in the reference, main.py:29-39); "
-                                      "convert to a pc_normal .npy first")
+            # main.py:29-39 -> mesh_to_pc.py:42-57: load the file, draw n_points surface points + the normal of the face under each
+            from .mesh_input import load_mesh, mesh_to_pc_normal
+            if mc:
+                raise NotImplementedError("--mc (mesh_to_pc.py:13-40: mesh2sdf signed distances + scikit-image marching cubes to make the "
+                                          "input watertight before sampling) needs mesh2sdf and scikit-image, which are not installed")
+            for input_path in input_list:
+                vertices, faces = load_mesh(input_path)
+                self.data.append({"pc_normal": mesh_to_pc_normal(vertices, faces, n_points), "uid": input_path.split("/")[-1].split(".")[0]})
         # any other value yields an empty dataset, like the reference's default 'pc' (main.py:70-75)
         print(f"dataset total data samples: {len(self.data)}")
 

@@ -237,6 +237,47 @@ def test_large_batches_all_mfma_tile_counts(B):
     assert torch.equal(out["tokens"], again["tokens"])
 
 
+@pytest.mark.parametrize("B,G", [(8, 2), (13, 3), (24, 4), (9, 2)])
+def test_large_batches_row_groups_equal_their_own_batches(B, G):
+    """decode_groups (opt-in: measured slower, profiles/r03_ab_row_groups.txt): the rows of a batch are cut into G groups that step
+    concurrently on their own streams (captured graph per group).  Nothing crosses a group, and on the matrix-core path a row's arithmetic depends only on the kernel forms its GROUP
+    size selects -- so group g of a grouped run must reproduce, bit for bit, an ungrouped run of just its rows; greedy, with
+    eos / pad bookkeeping, and sampled from injected uniforms."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle
+    cfg = MAConfig.tiny(dtype=DTYPE_BF16, max_batch=32)
+    sd = cached_state_dict(cfg)
+    oracle = Oracle(cfg, sd, "bf16", device=oracle_device())
+    eng = Engine(cfg)
+    eng.load_weights(sd.items())
+    x = clouds(cfg, list(range(300, 300 + B)))
+    prefix = oracle.process_point_feature(oracle.encode_latents(x)).cuda()
+    u = torch.rand(B, cfg.max_new_tokens, generator=torch.Generator().manual_seed(5))
+    eng.set_option("profile_batch", B)
+    for kw in (dict(suppress_eos=True), dict(check_every=5), dict(sampling=True, uniforms=u, suppress_eos=True)):
+        eng.set_option("decode_groups", G)
+        n_groups = eng.get_option("decode_groups")
+        assert n_groups == G
+        toks, lengths = eng.generate(prefix, **kw)
+        again, _ = eng.generate(prefix, **kw)
+        assert torch.equal(toks, again), "grouped generation is not deterministic"
+        eng.set_option("decode_groups", 1)
+        r0 = 0
+        for g in range(n_groups):
+            n = B // n_groups + (1 if g < B % n_groups else 0)
+            kw_g = dict(kw)
+            if "uniforms" in kw_g:
+                kw_g["uniforms"] = u[r0:r0 + n]
+            alone, len_alone = eng.generate(prefix[r0:r0 + n], **kw_g)
+            w = min(alone.shape[1], toks.shape[1])
+            for b in range(n):
+                m = min(int(lengths[r0 + b]), int(len_alone[b]))
+                assert int(lengths[r0 + b]) == int(len_alone[b]), f"group {g} row {b}: lengths differ ({kw.keys()})"
+                assert torch.equal(toks[r0 + b, :m], alone[b, :m]), f"group {g} (rows {r0}..{r0 + n - 1}) row {b} differs from its own batch ({list(kw)})"
+            r0 += n
+    eng.set_option("decode_groups", 1)
+
+
 def test_graph_eager_and_stepwise_prefill_agree(tiny):
     x = clouds(tiny.cfg, [10])
     prefix = tiny.oracle.process_point_feature(tiny.oracle.encode_latents(x)).cuda()
