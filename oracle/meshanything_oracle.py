@@ -626,3 +626,84 @@ def verify_sampled_stream(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Te
         else:
             hard.append((j, tok, pick))
     return {"n": n, "exact": exact, "ambiguous": ambiguous, "hard": hard}
+
+
+def classify_sampled_draws(logits: torch.Tensor, tokens: torch.Tensor, uniforms: torch.Tensor, tol: float, top_k: int = 50,
+                           top_p: float = 0.95) -> Dict[str, torch.Tensor]:
+    """`verify_sampled_stream`'s per-step decision for MANY steps at once, as tensor operations on `logits.device` (the scalar walk
+    costs a Python sort of the vocabulary per step: minutes for 64 rows x 100 steps at the 350M shape).  logits (N, V) with eos already
+    suppressed if it has to be; tokens (N,), uniforms (N,).  Same definitions: top-k keeps the k largest scores (descending, ties by
+    torch.topk's order -- a tie AT the k-th score is the one case the scalar walk treats differently: it keeps both); top-p removes the
+    ascending prefix whose cumulative mass is <= 1 - top_p and always keeps the largest; inverse CDF in descending order.
+    Returns boolean vectors `exact` (the oracle's own draw is the token), `ok` (the token's CDF interval, or the one with a single
+    candidate more / fewer kept when the top-p cut sits within tol of the boundary, contains the uniform within tol), and `distance`:
+    how far the uniform lies from the token's interval on the oracle's CDF (0 inside; a candidate the oracle's top-p cut removed, or one of
+    the 14 scores below the k-th, sits at the end of the CDF: distance 1 - u; any other token: inf).  The distance is the robust statistic when the
+    distribution is nearly flat (random-init weights: the top-50 logits span ~1.5, neighbours ~0.03 apart, so bf16 noise reorders them
+    and moves the top-p cut by more than one candidate)."""
+    N, V = logits.shape
+    k = min(top_k, V)
+    lg = logits.float()
+    tokens = tokens.to(lg.device).long()
+    u = uniforms.to(lg.device).float()
+    k_ext = min(V, k + 14)                                                                 # neighbourhood of the k-th score (see `distance`)
+    topv_e, topi_e = torch.topk(lg, k_ext, dim=-1, sorted=True)
+    topv, topi = topv_e[:, :k], topi_e[:, :k]
+    p_desc = torch.softmax(topv, dim=-1)
+    tail = torch.flip(torch.cumsum(torch.flip(p_desc, dims=[-1]), dim=-1), dims=[-1])      # tail[r] = mass of ranks r..k-1
+    keep = ~(tail <= (1.0 - top_p))
+    keep[:, 0] = True
+    nk = keep.sum(dim=-1)                                                                  # kept ranks are a prefix 0..nk-1
+    rank_ar = torch.arange(k, device=lg.device)[None, :]
+    is_tok = topi_e == tokens[:, None]
+    near_topk = is_tok.any(dim=-1)                                                         # among the k + 14 largest scores
+    tok_rank = torch.where(near_topk, is_tok.float().argmax(dim=-1), torch.full_like(nk, k_ext))
+
+    def interval(nkeep):
+        mask = rank_ar < nkeep[:, None]
+        probs = torch.softmax(torch.where(mask, topv, torch.full_like(topv, float("-inf"))), dim=-1)
+        # sample_from accumulates in fp32, one candidate at a time: a sequential cumsum
+        cdf = torch.cumsum(probs, dim=-1)
+        lo = torch.cat([torch.zeros(N, 1, device=lg.device), cdf[:, :-1]], dim=-1)
+        r = tok_rank.clamp(max=k - 1)
+        t_lo, t_hi = lo.gather(1, r[:, None])[:, 0], cdf.gather(1, r[:, None])[:, 0]
+        kept_tok = tok_rank < nkeep
+        # the oracle's own draw: first rank whose cumulative mass exceeds u, else the last kept one
+        over = (cdf > u[:, None]) & mask
+        first = torch.where(over.any(dim=-1), over.float().argmax(dim=-1), nkeep - 1)
+        return kept_tok, t_lo, t_hi, first
+
+    kept_tok, t_lo, t_hi, first = interval(nk)
+    exact = topi.gather(1, first[:, None])[:, 0] == tokens
+    ok = exact | (kept_tok & (t_lo - tol <= u) & (u <= t_hi + tol))
+    distance = torch.where(kept_tok, torch.maximum(t_lo - u, u - t_hi).clamp(min=0.0), 1.0 - u)
+    distance = torch.where(near_topk, distance, torch.full_like(distance, float("inf")))
+    for delta in (-1, 1):
+        nk_alt = nk + delta
+        valid = (nk_alt >= 1) & (nk_alt <= k)
+        r = torch.where(torch.full_like(nk, delta) > 0, nk, nk - 1).clamp(0, k - 1)      # rank of the candidate that changes sides
+        near = (tail.gather(1, r[:, None])[:, 0] - (1.0 - top_p)).abs() <= tol
+        kt, lo2, hi2, _ = interval(nk_alt.clamp(1, k))
+        ok = ok | (valid & near & kt & (lo2 - tol <= u) & (u <= hi2 + tol))
+    return {"exact": exact, "ok": ok, "distance": distance}
+
+
+def verify_sampled_batch(oracle: Oracle, prefix: torch.Tensor, tokens: torch.Tensor, uniforms: torch.Tensor, tol: float,
+                         suppress_eos: bool = False) -> Dict[str, object]:
+    """`verify_sampled_stream` for a batch: prefix (B, T, H), tokens (B, n), uniforms (B, n).  One teacher-forced pass per row on the
+    oracle's device, the per-draw decisions vectorised (classify_sampled_draws)."""
+    B, n = tokens.shape
+    rows = []
+    with oracle.on_device():
+        for b in range(B):
+            lg = oracle.teacher_forced_logits(prefix[b:b + 1], tokens[b])[:n]
+            if suppress_eos:
+                lg = lg.clone()
+                lg[:, EOS] = float("-inf")
+            rows.append(lg)
+    logits = torch.cat(rows)
+    c = classify_sampled_draws(logits, tokens.reshape(-1), uniforms.reshape(-1), tol)
+    exact, ok = c["exact"].cpu(), c["ok"].cpu()
+    bad = (~ok).nonzero().flatten().tolist()
+    return {"n": B * n, "exact": int(exact.sum()), "ambiguous": int((ok & ~exact).sum()), "hard": [(i // n, i % n) for i in bad],
+            "distance": c["distance"].cpu().reshape(B, n)}
