@@ -541,12 +541,13 @@ def test_full_length_generation_properties(full, golden_dir):
 
 
 def test_v2_scale_1600_faces(golden_dir):
-    """BASELINE.json config 5 shape (1600-face cap: 14402 new tokens, cache 14659 positions, 1.44 GB of KV per row in bf16):
+    """BASELINE.json configs[4] at its own shape (1600-face cap: 14402 new tokens, cache 14659 positions, 1.44 GB of KV per row in bf16,
+    batch 8):
     the longer cache stride, position table rows and 16-chunk attention split are exercised by a short batched decode that
     the oracle verifies, plus one step profiled deep into the cache."""
     from meshanything_amd.engine import Engine
     from oracle.meshanything_oracle import Oracle
-    cfg = MAConfig.full(dtype=DTYPE_BF16, n_max_faces=1600, max_batch=4)
+    cfg = MAConfig.full(dtype=DTYPE_BF16, n_max_faces=1600, max_batch=8)
     assert cfg.max_seq == 14659 and cfg.max_new_tokens == 14402
     env = Env.__new__(Env)
     env.cfg, env.policy = cfg, "bf16"
@@ -554,15 +555,15 @@ def test_v2_scale_1600_faces(golden_dir):
     env.oracle = Oracle(cfg, env.sd, "bf16", device=oracle_device())
     env.engine = Engine(cfg)
     load_weights_cached(env.engine, cfg)
-    x = mouse_variants(golden_dir, 4)
+    x = mouse_variants(golden_dir, 8)
     prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
     toks, lengths = env.engine.generate(prefix.cuda(), max_new_tokens=96, suppress_eos=True)
-    assert toks.shape == (4, 96)
+    assert toks.shape == (8, 96)
     v = _check_greedy(env, prefix, toks, lengths, suppress_eos=True)
     assert all(r["ambiguous"] <= 4 for r in v), [r["ambiguous"] for r in v]
-    env.engine.set_option("profile_batch", 4)
+    env.engine.set_option("profile_batch", 8)
     p = env.engine.profile_decode(cfg.max_seq - 64, 2)              # a step with ~14.6k cached positions per row
-    print(f"[1600 faces, batch 4] decode step at kv_len {cfg.max_seq - 64}: {p['step_ms_graph']:.3f} ms")
+    print(f"[1600 faces, batch 8] decode step at kv_len {cfg.max_seq - 64}: {p['step_ms_graph']:.3f} ms")
     assert 0 < p["step_ms_graph"] < 50
 
 
