@@ -1905,7 +1905,8 @@ int ma_profile_decode(ma_engine* e, int kv_len, int steps, ma_kernel_timing* out
         // One event pair around `steps` back-to-back steps (no per-launch events: an event record between two launches
         // costs more than the launch boundary it would measure).  only_cls >= 0 enqueues just that class of launches, so
         // class time / launches is the average launch duration, boundary to the next launch included -- the same view as
-        // a rocprofv3 kernel trace of the replayed graph.  only_cls == -2: graph replays.
+        // a rocprofv3 kernel trace of the replayed graph.  only_cls == -2: graph replays (with row groups on their streams when
+        // decode_groups > 1; the per-class and eager figures are always one ungrouped chain on `s`).
         auto timed = [&](int only_cls, int* launches) -> float {
             StepTimer tm; tm.only_cls = only_cls;
             reset();
