@@ -98,6 +98,42 @@ def dense_phase_table(eng, cfg: MAConfig, batches=(16, 64), iters: int = 3):
     return out
 
 
+def measured_peaks(eng):
+    """What THIS box reaches on the two roofline denominators, next to the vendor numbers the fractions are
+    quoted against: a 16-byte-per-lane streaming copy of 2 x 1 GiB (ma_op_stream_copy; read + write bytes) and the library's dense bf16
+    GEMM on 8192^3 uniform random [-1, 1) operands (ma_op_gemm_bf16)."""
+    import ctypes as C
+    lib = eng.lib
+    cur = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 255)
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps * 1e-3
+    t_copy = timed(lambda: lib.ma_op_stream_copy(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), C.c_size_t(n), cur), 10)
+    del a, b
+    M = 8192
+    A = (torch.rand(M, M, device="cuda") * 2 - 1).to(torch.bfloat16)
+    W = (torch.rand(M, M, device="cuda") * 2 - 1).to(torch.bfloat16)
+    Cb = torch.empty(M, M, dtype=torch.bfloat16, device="cuda")
+    z = C.c_void_p(0)
+    t_gemm = timed(lambda: lib.ma_op_gemm_bf16(C.c_void_p(A.data_ptr()), M, C.c_void_p(W.data_ptr()), z, z, 0, z, 0, C.c_void_p(Cb.data_ptr()), M, M, M, M, 0, cur), 5)
+    del A, W, Cb
+    torch.cuda.empty_cache()
+    return {"stream_copy_GBps": round(2 * n / t_copy / 1e9, 1), "stream_copy_frac_of_8TBps": round(2 * n / t_copy / 1e9 / HBM_PEAK_GBS, 4),
+            "gemm_bf16_8192_TFLOPs": round(2 * M ** 3 / t_gemm / 1e12, 1), "gemm_bf16_frac_of_2500TF": round(2 * M ** 3 / t_gemm / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "note": "measured by this run on this box (HIP events); the roofline fractions in this line stay quoted against the vendor peaks 8000 GB/s / 2500 TFLOP/s"}
+
+
 def plan(gpus: int, batch: int, rank: int, world: int, faces: int = 800, dtype: str = "bf16", sampling: bool = False, tokens_per_shape: int = 7202):
     """What this rank runs (pure: no GPU, no process group -- tests/test_bench_plan.py checks it for world sizes 1..8).
     BASELINE.json's metric is "batch=1 and batch=8xN shapes": `--gpus 1` decodes ONE shape (configs[1]); `--gpus N > 1` gives every
@@ -207,7 +243,9 @@ def main():
     t_load = time.time()
 
     def items():                                            # only called on rank 0
-        sd.update(synthetic_state_dict(cfg))                # random-init weights in the reference key layout (no network)
+        # random-init weights in the reference key layout (no network).  init="diverse": the default init's greedy stream is ONE token
+        # for ever (checkpoint.py); this one depends on its own tokens and positions -- `tokens_distinct` in the JSON line shows it
+        sd.update(synthetic_state_dict(cfg, init="diverse"))
         return sd.items()
     # weights travel once, rank 0 -> all, as ONE RCCL broadcast of the packed arena over xGMI
     dp.load_weights_dp(eng, items, rank, world, force_broadcast=use_dist)
@@ -245,6 +283,17 @@ def main():
         dt = float(t.item())
     tokens_per_step = cfg.max_new_tokens * args.batch
     assert tuple(out["tokens"].shape) == (args.batch, cfg.max_new_tokens)
+    tokens_distinct = [len(set(r.tolist())) for r in out["tokens"].cpu()]
+    # health of the fused decode launches over everything this engine ran so far (a generation that lost them was re-run on the
+    # five-launch chain: correct, slower, and visible here)
+    health = {"chain_resident": eng.get_option("chain_resident"), "chain_fallbacks": eng.get_option("chain_fallbacks"), "xchg_timeouts": eng.get_option("xchg_timeouts")}
+    # encoder activations of shape 0 (mouse.npy) against the reference's own perceiver (tests/golden/full.npz; the encoder weights of
+    # init="diverse" are the default ones): the north star's 1e-5
+    enc_err = None
+    if rank == 0 and pl["shapes"][0] == 0:
+        gold = np.load(os.path.join(REPO, "tests", "golden", "full.npz"))
+        lat0 = out["latents"][0].cpu().numpy()
+        enc_err = float(max(np.abs(lat0[gold["full_rows"]] - gold["full_latents_rows"]).max(), np.abs(lat0[:, :8] - gold["full_latents_cols8"]).max()))
 
     if rank == 0:
         esz = 2 if args.dtype == "bf16" else 4
@@ -311,6 +360,8 @@ def main():
                     "decode_step_ms_graph": round(prof["step_ms_graph"], 4), "decode_step_ms_eager": round(prof["step_ms_eager"], 4),
                     "decode_step_GBps_at_mid_context": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
                     "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        health_after = {"chain_resident": eng.get_option("chain_resident"), "chain_fallbacks": eng.get_option("chain_fallbacks"), "xchg_timeouts": eng.get_option("xchg_timeouts")}
+        peaks = measured_peaks(eng)
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))
@@ -357,9 +408,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": pl["workload"],
                        "global_batch": pl["global_batch"], "tokens_per_mesh": cfg.max_new_tokens, "parallelism": pl["parallelism"],
-                       "weights": "seeded random init in the reference key layout (no checkpoint available offline)"},
+                       "weights": "seeded random init in the reference key layout (no checkpoint available offline), init=diverse: checkpoint.py"},
             "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "dense_phases": dense, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
             "weights_load_s": round(t_load, 2), "fp32_exact": fp32_exact, "roofline": roofline, "cpu_baseline": cpu,
+            "tokens_distinct": tokens_distinct, "encoder_max_abs_err": enc_err, "fused_launch_health": {"timed_region": health, "after_profiling": health_after},
+            "measured_peaks": peaks,
         }
         if real_stdout is not None:
             os.write(real_stdout, (json.dumps(res) + "\n").encode())

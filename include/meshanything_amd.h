@@ -104,6 +104,13 @@ typedef struct ma_sample_cfg {
     uint64_t seed;          /* in-kernel uniform stream when `uniforms` is NULL */
     const float *uniforms;  /* DEVICE (B, max_new_tokens) uniforms in [0,1), or NULL.  Injected uniforms define
                                sampling parity with the oracle (the reference's Philox stream is not reproducible). */
+    /* teacher forcing (parity along the REFERENCE's own token path, tests/test_gpu_reference_anchor.py): when non-NULL, step t still
+     * picks its token from its logits and reports it in `tokens`, but the token FED to step t + 1 is forced_tokens[b][t] -- the engine
+     * walks the given stream and `tokens` shows what it would have chosen at every step of it.  A forced eos finishes the row. */
+    const int64_t *forced_tokens;   /* DEVICE (B, max_new_tokens) int64, or NULL */
+    /* when non-NULL, the logits every generated token was picked from: DEVICE (B, max_new_tokens, codebook_size + 3) fp32, row [b][t] =
+     * the distribution of token t (as returned by ma_engine_read_logits for the last step; eos is NOT masked in the copy) */
+    float *logits_out;
 } ma_sample_cfg;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------------- */
@@ -264,7 +271,12 @@ MA_API int  ma_op_rows_prologue(int pro, const float *x, int nparts, int B, cons
  * reference counterpart (the reference never shares a device between streams). */
 MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, const int32_t *release, void *stream);
 
-/* ---- persistent decode step (csrc/persist.hpp): the whole batch-1 greedy step as ONE resident launch instead of the
+/* ---- measurement aid: dst[0, bytes) = src[0, bytes) as a 16-byte-per-lane streaming copy (2048 blocks, grid-stride); bytes % 16 == 0.  bench.py
+ * times it to report the box's achievable HBM rate next to the 8 TB/s vendor number.  No reference counterpart. */
+MA_API int  ma_op_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
+
+/* ---- persistent decode step (csrc/persist.hpp; only in libraries built with MA_EXPERIMENTAL=1 -- measured 1.3-1.6x slower than the launch
+ * chain; the product build answers MA_ERR_STATE / 0): the whole batch-1 greedy step as ONE resident launch instead of the
  * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()
  * and the call is batch 1 / greedy, otherwise the chain runs.  replaces: the same reference calls as ma_generate's steps
  * (shape_opt.py:318-364,403-410,155; meshanything.py:143-151). */

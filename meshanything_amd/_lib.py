@@ -11,7 +11,12 @@ import os
 from .config import CMAConfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmeshanything_amd_debug.so" if os.environ.get("MA_DEBUG", "") not in ("", "0") else "libmeshanything_amd.so")   # build.py: the debug variant
+def _on(var: str) -> bool:
+    return os.environ.get(var, "") not in ("", "0")
+
+
+# build.py: MA_DEBUG selects the debug variant, MA_EXPERIMENTAL the one that also carries the rejected decode-step forms
+LIB_PATH = os.path.join(HERE, "libmeshanything_amd" + ("_debug" if _on("MA_DEBUG") else "") + ("_exp" if _on("MA_EXPERIMENTAL") else "") + ".so")
 
 MA_OK = 0
 ERR_NAMES = {0: "MA_OK", -1: "MA_ERR_INVALID", -2: "MA_ERR_HIP", -3: "MA_ERR_STATE", -4: "MA_ERR_UNKNOWN_TENSOR",
@@ -33,7 +38,7 @@ class TensorDesc(C.Structure):
 class SampleCfg(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_float),
                 ("max_new_tokens", C.c_int32), ("suppress_eos", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32),
-                ("seed", C.c_uint64), ("uniforms", C.c_void_p)]
+                ("seed", C.c_uint64), ("uniforms", C.c_void_p), ("forced_tokens", C.c_void_p), ("logits_out", C.c_void_p)]
 
 
 class KernelTiming(C.Structure):
@@ -84,6 +89,7 @@ SIGNATURES = {
     "ma_op_gemm_dec_qkv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_size_t, _P]),
     "ma_op_rows_prologue": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _P]),
     "ma_op_occupy_cus": (_I, [_I, _I, C.c_int64, _P, _P]),
+    "ma_op_stream_copy": (_I, [_P, _P, C.c_size_t, _P]),
     "ma_engine_persist_available": (_I, [_P]),
     "ma_persist_trace": (_I, [_P, _I, _P, C.POINTER(C.c_int32), _P]),
     "ma_engine_read_logits": (_I, [_P, _I, _P, _P]),

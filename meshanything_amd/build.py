@@ -1,7 +1,7 @@
 """Build the gfx950 HIP library in-tree (hipcc cross-compiles without a GPU).
 
 The library is rebuilt whenever the SHA-256 over every source it is compiled from (csrc/*.hip, csrc/*.hpp, the public
-header, the flags, the compiler's version line) differs from the hash compiled INTO it (`ma_version()` ends in `src=<hash>`; a
+header, the flags -- NOT the compiler: a hipcc / ROCm upgrade needs `build(force=True)`) differs from the hash compiled INTO it (`ma_version()` ends in `src=<hash>`; a
 copy is kept in a side file so that `needs_build()` does not have to dlopen).  `_lib.load()` refuses a library whose embedded
 hash does not match the tree it sits in (a stale .so would otherwise travel to the GPU box silently: it is git-ignored, not
 gpurun-ignored); a packaged library without the sources next to it is not checked, and MA_ALLOW_STALE_LIB=1 downgrades the
@@ -23,9 +23,12 @@ HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "meshanything_amd.
 # MA_DEBUG=1 selects the debug variant ("race detection / sanitizers"): -O1 -g, device-side assert()s alive
 # (the release build defines NDEBUG), its own file name so the two never shadow each other; `_lib.load()` follows the same variable.
 # MA_DEBUG=asan additionally asks for HIP AddressSanitizer (host + device instrumentation; needs an xnack+ capable setup).
+# MA_EXPERIMENTAL=1 compiles the measured-and-rejected decode-step forms in as well (persist.hpp, rows_fused.hpp, layer_fused.hpp,
+# the dense GEMM's A/B variants); the product build leaves them out.  Its own file name, like the debug variant.
+EXPERIMENTAL = os.environ.get("MA_EXPERIMENTAL", "") not in ("", "0")
 DEBUG = os.environ.get("MA_DEBUG", "") not in ("", "0")
 ASAN = os.environ.get("MA_DEBUG", "") == "asan"
-OUT = os.path.join(HERE, "libmeshanything_amd_debug.so" if DEBUG else "libmeshanything_amd.so")
+OUT = os.path.join(HERE, "libmeshanything_amd" + ("_debug" if DEBUG else "") + ("_exp" if EXPERIMENTAL else "") + ".so")
 HASH_FILE = OUT + ".srchash"
 _COMMON = ["-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-unused-result"]
 if ASAN:
@@ -34,6 +37,8 @@ elif DEBUG:
     FLAGS = ["--offload-arch=gfx950", "-O1", "-g", "-DMA_DEBUG=1"] + _COMMON
 else:
     FLAGS = ["--offload-arch=gfx950", "-O3", "-DNDEBUG"] + _COMMON
+if EXPERIMENTAL:
+    FLAGS = FLAGS + ["-DMA_EXPERIMENTAL=1"]
 
 
 def source_files():

@@ -180,6 +180,14 @@ __device__ __forceinline__ bool xchg_expired(unsigned& spins, u64 t0, const unsi
     return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
+// a sweep gave up: raise the bit in the engine's error word (err[0]; read and cleared by the host after the first step and after every
+// burst) and count the event in err[1], which is never cleared -- the total shows in ma_engine_get_option("xchg_timeouts") and in the
+// bench line, so a run that lost its fused launches for a while cannot look like a clean one
+__device__ __forceinline__ void xchg_raise(unsigned* err, unsigned code) {
+    __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

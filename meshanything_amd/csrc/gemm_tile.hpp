@@ -38,8 +38,6 @@ struct GemmTArgs {
     int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
     RowMap cmap;                    // output row of logical row m
     int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
-    int m_begin;                    // first row this launch computes (rows [m_begin, M)): launch_gemm_tile peels a ragged tail of rows off
-                                    // into a second launch so that the bulk fills whole rounds of resident blocks
 };
 
 __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
         const int t = xcd * lo + min(xcd, rem) + i;
         tile_y = t / NT; tile_x = t - tile_y * NT;
     }
-    const int bm = g.m_begin + tile_y * BM, bn = tile_x * BN;
+    const int bm = tile_y * BM, bn = tile_x * BN;
     const unsigned lds0 = (unsigned)(size_t)gt_smem;
 
     // ---- DMA addressing: instruction p of an operand covers tile rows p * RPI .. + RPI - 1; lane -> (row, slot) -----------
@@ -206,7 +204,7 @@ inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M - g.m_begin + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
+    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
     return hipGetLastError();
 }
 

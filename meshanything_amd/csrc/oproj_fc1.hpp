@@ -155,7 +155,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             if (!pend) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
 #pragma unroll
                 for (int k = 0; k < NK; ++k) yr[k * 64 + lane] = 0.f;
                 break;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { fr[2 * (k * 64 + lane)] = 0.f; fr[2 * (k * 64 + lane) + 1] = 0.f; }
                     break;
@@ -294,7 +294,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) __hip_atomic_fetch_or(a.err, OF_ERR_GATHER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) yr[k * 64 + lane] = 0.f;
                     break;

@@ -18,6 +18,8 @@ struct DecState {
     const float* uniforms;   // (max_new_tokens) uniforms of this row, or null -> hashed from seed
     int row;                 // batch row (decorrelates the hashed uniform stream)
     int max_new;
+    const long long* forced; // (max_new_tokens) tokens of this row to feed instead of the picked ones (teacher forcing), or null
+    float* logits_out;       // (max_new_tokens, V) of this row: the logits of every step, or null
 };
 
 // weights of one OPT decoder layer inside the arena ([3p] OPTDecoderLayer; q/k/v fused into one [3H][H] matrix at load)

@@ -153,7 +153,8 @@ class Engine:
         return out
 
     def _sample_cfg(self, sampling: bool, max_new_tokens: Optional[int], suppress_eos: bool, uniforms: Optional[torch.Tensor],
-                    seed: int, check_every: int, top_k: int, top_p: float) -> Tuple[_lib.SampleCfg, object]:
+                    seed: int, check_every: int, top_k: int, top_p: float, forced_tokens: Optional[torch.Tensor] = None,
+                    logits_out: Optional[torch.Tensor] = None) -> Tuple[_lib.SampleCfg, object]:
         sc = _lib.SampleCfg()
         sc.struct_size = C.sizeof(_lib.SampleCfg)
         sc.do_sample = 1 if sampling else 0
@@ -162,28 +163,40 @@ class Engine:
         sc.suppress_eos = 1 if suppress_eos else 0
         sc.check_every = check_every
         sc.seed = seed
-        keep = None
+        keep = []
         if uniforms is not None:
-            keep = uniforms.to(self.device, torch.float32).contiguous()
-            sc.uniforms = keep.data_ptr()
+            keep.append(uniforms.to(self.device, torch.float32).contiguous())
+            sc.uniforms = keep[-1].data_ptr()
+        if forced_tokens is not None:
+            keep.append(forced_tokens.to(self.device, torch.int64).contiguous())
+            sc.forced_tokens = keep[-1].data_ptr()
+        if logits_out is not None:
+            sc.logits_out = logits_out.data_ptr()
         return sc, keep
 
     def generate(self, prefix: torch.Tensor, sampling: bool = False, max_new_tokens: Optional[int] = None,
                  suppress_eos: bool = False, uniforms: Optional[torch.Tensor] = None, seed: int = 0, check_every: int = 64,
-                 top_k: int = 50, top_p: float = 0.95) -> Tuple[torch.Tensor, np.ndarray]:
-        """transformer.generate(inputs_embeds=prefix, ...) (meshanything.py:143-162) -> (tokens (B, n_generated), lengths)."""
+                 top_k: int = 50, top_p: float = 0.95, forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+        """transformer.generate(inputs_embeds=prefix, ...) (meshanything.py:143-162) -> (tokens (B, n_generated), lengths).
+        forced_tokens (B, max_new_tokens): teacher forcing -- the returned tokens are the engine's own picks at every step of the GIVEN
+        stream (ma_sample_cfg.forced_tokens).  return_logits: also returns the (B, max_new_tokens, vocab) fp32 logits of every step."""
         cfg = self.cfg
         prefix = prefix.to(self.device, torch.float32).contiguous()
         B = prefix.shape[0]
         maxn = int(max_new_tokens or cfg.max_new_tokens)
         if uniforms is not None:
             assert tuple(uniforms.shape) == (B, maxn), (uniforms.shape, (B, maxn))
-        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p)
+        if forced_tokens is not None:
+            assert tuple(forced_tokens.shape) == (B, maxn), (forced_tokens.shape, (B, maxn))
+        logits = torch.zeros(B, maxn, cfg.vocab, dtype=torch.float32, device=self.device) if return_logits else None
+        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p, forced_tokens, logits)
         tokens = torch.empty(B, cfg.max_new_tokens, dtype=torch.int64, device=self.device)
         lengths = (C.c_int32 * B)()
         ngen = C.c_int32()
         self._check(self.lib.ma_generate(self.h, _ptr(prefix), B, C.byref(sc), _ptr(tokens), lengths, C.byref(ngen), _stream_ptr()))
         del keep
+        if return_logits:
+            return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32), logits[:, :ngen.value]
         return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32)
 
     def postprocess_tokens(self, results: torch.Tensor) -> torch.Tensor:

@@ -28,6 +28,10 @@ from meshanything_amd.config import MAConfig            # noqa: E402
 from meshanything_amd.checkpoint import synthetic_state_dict, PE, SM, DEC, TOK  # noqa: E402
 
 
+# the anchors of full_anchor_hf.npz: (tag, seed, init of synthetic_state_dict, how the token path is chosen)
+ANCHOR_HF_SETS = (("dva", 1234, "diverse", "greedy"), ("hfa", 1234, "hf", "sampled"))
+
+
 def _stub_modules():
     for name in ("omegaconf", "trimesh", "skimage", "skimage.measure", "cv2", "mesh2sdf", "mesh2sdf.core"):
         try:
@@ -416,6 +420,135 @@ def golden_anchor(out, cfg: MAConfig, sd, lat: torch.Tensor, prefix: torch.Tenso
     print(f"anchor detok: {int(out['anchor_detok_valid'].sum())} valid faces, margin quantiles 1% {np.quantile(m, 0.01):.4f} 10% {np.quantile(m, 0.1):.4f} 50% {np.quantile(m, 0.5):.4f}")
 
 
+def golden_anchor_diverse(out, cfg: MAConfig, sd, tag: str, mouse: np.ndarray, mode: str, steps: int = 256):
+    """Reference-anchored 350M numbers on a NON-DEGENERATE token stream (the default synthetic checkpoint has a
+    fixed point, so `full_anchor.npz` walks a constant stream; an HF-style N(0, 0.02) one cycles through 3 ids -- checkpoint.py,
+    init="diverse", says why).  Two ways to a diverse stream, both driven by the REFERENCE's modules on pc_examples/mouse.npy:
+      mode "greedy"  (weights init="diverse"): `steps` + 1 greedy tokens through ShapeOPTDecoder.forward, eos suppressed;
+      mode "sampled" (weights init="hf", what the reference's constructors leave): the tokens are DRAWN from the reference's own
+                     distribution -- transformers' TopKLogitsWarper(50) -> TopPLogitsWarper(0.95), the chain generate(do_sample=True)
+                     builds (meshanything.py:153-162) -- by inverse CDF (descending probability, ties by ascending id, fp32 running
+                     sum) from seeded uniforms that are stored with the stream.
+    Asserted: >= 32 distinct ids.  Recorded per step, fp32: the token fed next, the argmax, the top-16 logits, the top-1/top-2 margin,
+    every 64th column; the perceiver's latents / the prefix (rows + 8 columns) on these weights; the detokenizer's bins and margins; and
+      * the SAME token path under `torch.autocast("cpu", dtype=torch.float16)` -- the reference's own precision policy
+        (main.py:114-118,149: Accelerator(mixed_precision="fp16") + accelerator.autocast()): fp16 Linear inputs / weights / outputs and an
+        fp16 KV cache, fp32 LayerNorm and residual stream.  (Attention is transformers' eager path here, which rounds the scores and
+        probabilities to fp16; flash-attn keeps them fp32 inside the kernel -- the fixture is the reference's precision CLASS, not
+        its flash kernel.)  Stored: the logits at the fp32 top-16 indices and columns, the fp16 argmax and margin per step."""
+    assert mode in ("greedy", "sampled")
+    from transformers.generation.logits_process import TopKLogitsWarper, TopPLogitsWarper
+    from MeshAnything.models.meshanything import NoiseResistantDecoder, MeshAnything as RefMeshAnything
+    scratch = {}
+    rows = [0, 1, 2, 3, 100, 255, 256]
+    lat, prefix = golden_encoder(scratch, cfg, sd, "e", mouse, rows=rows)
+    for k in ("rows", "latents_rows", "latents_cols8", "prefix_rows", "prefix_cols8", "stats"):
+        out[f"{tag}_{k}"] = scratch[f"e_{k}"]
+    dec, lm_head = build_ref_decoder(cfg, sd)
+    B, T = 1, cfg.cond_length
+    cols = np.arange(0, cfg.vocab, 64)
+    toks, top_i, top_v, margin, lcols = [], [], [], [], []
+
+    uni = torch.rand(steps + 1, generator=torch.Generator().manual_seed(2024)).numpy().astype(np.float32)
+    warp_k, warp_p = TopKLogitsWarper(top_k=50), TopPLogitsWarper(top_p=0.95)
+    kept_n = []
+
+    def record(h):
+        lg = (h.float() @ lm_head.T)[0].clone()
+        lg[1] = float("-inf")
+        tv, ti = torch.topk(lg, 16)
+        top_i.append(ti.numpy()); top_v.append(tv.numpy()); margin.append(float(tv[0] - tv[1]))
+        lcols.append(lg[cols].numpy())
+        tok = int(ti[0])
+        if mode == "sampled":
+            sc = warp_p(None, warp_k(None, lg[None].clone()))
+            probs = torch.softmax(sc, dim=-1)[0]
+            kept = torch.nonzero(probs > 0).flatten().tolist()
+            kept.sort(key=lambda i: (-float(lg[i]), i))
+            kept_n.append(len(kept))
+            acc, u, tok = torch.zeros((), dtype=torch.float32), float(uni[len(toks)]), kept[-1]
+            for i in kept:
+                acc = acc + probs[i]
+                if float(acc) > u:
+                    tok = i
+                    break
+        toks.append(tok)
+        return tok
+    with torch.no_grad():
+        o = dec(inputs_embeds=prefix, attention_mask=torch.ones(B, T, dtype=torch.long), use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        tok = record(o.last_hidden_state[:, -1])
+        for t in range(1, steps + 1):
+            o = dec(input_ids=torch.tensor([[tok]]), past_key_values=pkv, attention_mask=torch.ones(B, T + t, dtype=torch.long),
+                    use_cache=True, return_dict=True)
+            pkv = o.past_key_values
+            tok = record(o.last_hidden_state[:, -1])
+    distinct = len(set(toks))
+    assert distinct >= 32, f"the {tag} stream has only {distinct} distinct tokens: not a diverse anchor"
+    out[f"{tag}_mode"] = np.array([0 if mode == "greedy" else 1])
+    out[f"{tag}_uniforms"] = uni
+    if mode == "sampled":
+        out[f"{tag}_kept"] = np.array(kept_n, dtype=np.int32)
+    out[f"{tag}_tokens"] = np.array(toks, dtype=np.int64)
+    out[f"{tag}_top_idx"] = np.stack(top_i).astype(np.int32)
+    out[f"{tag}_top_val"] = np.stack(top_v).astype(np.float32)
+    out[f"{tag}_margin"] = np.array(margin, dtype=np.float32)
+    out[f"{tag}_cols"] = cols.astype(np.int32)
+    out[f"{tag}_logits_cols"] = np.stack(lcols).astype(np.float32)
+    print(f"anchor[{tag}] fp32: {steps + 1} tokens, {distinct} distinct, margin min {min(margin):.5f} 10% {np.quantile(margin, 0.1):.4f} median {float(np.median(margin)):.4f}")
+    # ---- the same path under fp16 autocast (teacher-forced on the fp32 tokens) ----
+    h_top, h_cols, h_arg, h_margin = [], [], [], []
+    lm16 = lm_head.half()
+
+    def record16(h, j):
+        # lm_head is an nn.Linear in the reference (shape_opt.py:24,155): autocast runs it in fp16 as well
+        lg = torch.nn.functional.linear(h, lm16)[0].float()
+        lg[1] = float("-inf")
+        tv, ti = torch.topk(lg, 2)
+        h_arg.append(int(ti[0])); h_margin.append(float(tv[0] - tv[1]))
+        h_top.append(lg[torch.from_numpy(top_i[j]).long()].numpy()); h_cols.append(lg[cols].numpy())
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        o = dec(inputs_embeds=prefix, attention_mask=torch.ones(B, T, dtype=torch.long), use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        assert pkv[0][0].dtype == torch.float16                    # the KV cache of the reference's policy
+        record16(o.last_hidden_state[:, -1].half(), 0)
+        for t in range(1, steps + 1):
+            o = dec(input_ids=torch.tensor([[toks[t - 1]]]), past_key_values=pkv, attention_mask=torch.ones(B, T + t, dtype=torch.long),
+                    use_cache=True, return_dict=True)
+            pkv = o.past_key_values
+            record16(o.last_hidden_state[:, -1].half(), t)
+    out[f"{tag}_f16_top_val"] = np.stack(h_top).astype(np.float32)
+    out[f"{tag}_f16_logits_cols"] = np.stack(h_cols).astype(np.float32)
+    out[f"{tag}_f16_argmax"] = np.array(h_arg, dtype=np.int64)
+    out[f"{tag}_f16_margin"] = np.array(h_margin, dtype=np.float32)
+    err16 = float(np.abs(out[f"{tag}_f16_top_val"] - out[f"{tag}_top_val"]).max())
+    agree = float(np.mean(np.array(h_arg) == np.stack(top_i)[:, 0]))
+    print(f"anchor[{tag}] fp16 autocast along the fp32 path: max |logit - fp32| over the top-16 {err16:.5f}, argmax agreement {agree * 100:.2f} %")
+    # ---- detokenizer on these weights ----
+    args = types.SimpleNamespace(codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim)
+    tok_m = NoiseResistantDecoder(args)
+    sub = {k[len(TOK):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith(TOK)}
+    tok_m.load_state_dict(sub, strict=True)
+    tok_m.eval()
+    ids = torch.from_numpy(np.load(os.path.join(HERE, "full.npz"))["full_detok_ids"])
+    ns = types.SimpleNamespace(num_quantizers=3)
+    ns.transformer = types.SimpleNamespace(model=types.SimpleNamespace(decoder=types.SimpleNamespace(
+        quantize_codebooks=torch.from_numpy(sd[DEC + "quantize_codebooks"]))))
+    seen = {}
+    hook = tok_m.to_coor_logits.register_forward_hook(lambda mod, inp, res: seen.__setitem__("logits", res.detach().clone()))
+    with torch.no_grad():
+        codes = RefMeshAnything.get_codes(ns, ids)
+        coords = tok_m(ids, codes, point_feature=lat)
+    hook.remove()
+    lg = seen["logits"][0]
+    tv, ti = torch.topk(lg, 2, dim=-1)
+    out[f"{tag}_detok_bins"] = ti[..., 0].numpy().astype(np.int16)
+    out[f"{tag}_detok_margin"] = (tv[..., 0] - tv[..., 1]).numpy().astype(np.float32)
+    out[f"{tag}_detok_valid"] = (~torch.isnan(coords[0, :, 0, 0])).numpy()
+    m = out[f"{tag}_detok_margin"][out[f"{tag}_detok_valid"]]
+    print(f"anchor[{tag}] detok: {int(out[f'{tag}_detok_valid'].sum())} valid faces, margin quantiles 1% {np.quantile(m, 0.01):.4f} 50% {np.quantile(m, 0.5):.4f}")
+
+
 def golden_shapeopt_generate(out, cfg: MAConfig, sd):
     """THE OUTERMOST COMPOSITION: the reference's own `ShapeOPT` CausalLM wrapper
     (shape_opt.py:18-178) -> ShapeOPTModel -> ShapeOPTDecoder.forward, driven by the container's `GenerationMixin.generate` with the
@@ -588,6 +721,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, "shapeopt_generate.npz"), **g)
         print("shapeopt_generate.npz", os.path.getsize(os.path.join(HERE, "shapeopt_generate.npz")) // 1024, "KiB")
         return
+    if "--only-anchor-hf" in sys.argv:                    # 350M-shape reference numbers on diverse streams (two HF-style weight sets)
+        full = MAConfig.full()
+        mouse = np.load(os.path.join(HERE, "dataset.npz"))["mouse_norm"]
+        g = {}
+        for tag, seed, init, mode in ANCHOR_HF_SETS:
+            golden_anchor_diverse(g, full, synthetic_state_dict(full, seed=seed, include_unused=True, init=init), tag, mouse, mode)
+        np.savez_compressed(os.path.join(HERE, "full_anchor_hf.npz"), **g)
+        print("full_anchor_hf.npz", os.path.getsize(os.path.join(HERE, "full_anchor_hf.npz")) // 1024, "KiB")
+        return
     if "--only-anchor" in sys.argv:                       # 350M-shape reference numbers for the bf16 engine's logits / bins
         full = MAConfig.full()
         sd_f = synthetic_state_dict(full, include_unused=True)
@@ -633,7 +775,11 @@ def main():
     g = {}
     golden_anchor(g, full, sd_f, lat_f, prefix_f)
     np.savez_compressed(os.path.join(HERE, "full_anchor.npz"), **g)
-    for f in ("dataset.npz", "tiny.npz", "full.npz", "shapeopt_generate.npz", "full_anchor.npz"):
+    g = {}
+    for tag, seed, init, mode in ANCHOR_HF_SETS:
+        golden_anchor_diverse(g, full, synthetic_state_dict(full, seed=seed, include_unused=True, init=init), tag, mouse, mode)
+    np.savez_compressed(os.path.join(HERE, "full_anchor_hf.npz"), **g)
+    for f in ("dataset.npz", "tiny.npz", "full.npz", "shapeopt_generate.npz", "full_anchor.npz", "full_anchor_hf.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

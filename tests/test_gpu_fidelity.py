@@ -49,9 +49,9 @@ def test_fidelity_bf16_stream_vs_fp32_oracle(golden_dir):
     from meshanything_amd.engine import Engine
     from oracle.meshanything_oracle import Oracle
     cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=1)
-    sd = cached_state_dict(cfg)
+    sd = cached_state_dict(cfg, init="diverse")          # a stream that depends on its own tokens (the default init sits in a fixed point)
     eng = Engine(cfg)
-    load_weights_cached(eng, cfg)
+    load_weights_cached(eng, cfg, init="diverse")
     x = _mouse(golden_dir)
     out = eng.forward(x.cuda(), suppress_eos=True)
     toks = out["tokens"][0].cpu()
@@ -60,10 +60,12 @@ def test_fidelity_bf16_stream_vs_fp32_oracle(golden_dir):
     prefix32 = ofp.process_point_feature(ofp.encode_latents(x))             # what the fp32 reference arithmetic feeds the decoder
     # the whole 7202-token stream when the oracle runs on the GPU (a second of torch-ROCm work); capped when it is on host cores
     n = int(os.environ.get("MA_TEST_FIDELITY_TOKENS", str(cfg.max_new_tokens if oracle_device() != "cpu" else 1500)))
-    rate, first, margin, lost = _report("bf16 engine vs fp32 oracle, default init", ofp, prefix32, toks[:n])
-    # sanity only: a correct bf16 engine agrees with fp32 on the overwhelming majority of teacher-forced steps, and where it
+    rate, first, margin, lost = _report("bf16 engine vs fp32 oracle, init=diverse", ofp, prefix32, toks[:n])
+    print(f"[fidelity] distinct ids in the stream: {len(set(toks.tolist()))}")
+    assert len(set(toks.tolist())) >= 256
+    # sanity only: a correct bf16 engine agrees with fp32 on the large majority of teacher-forced steps, and where it
     # does not, fp32 itself was nearly undecided
-    assert rate > 0.97
+    assert rate > 0.80
     assert lost.numel() == 0 or float(lost.max()) < 0.25
     eng.close()
 

@@ -18,14 +18,19 @@ def eng(golden_dir):
     from meshanything_amd.engine import Engine
     cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=2)
     e = Engine(cfg)
-    load_weights_cached(e, cfg)
-    if not e.persist_available():
-        pytest.skip("persistent decode step not available on this device (needs 256 CUs)")
+    load_weights_cached(e, cfg, init="diverse")           # a greedy stream that depends on its own tokens (checkpoint.py)
     d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
     x = torch.from_numpy(d["mouse_norm"])[None]
     _, prefix = e.encode(x.cuda())
     e.prefix = prefix
     return e
+
+
+def _need_persist(eng):
+    if not eng.get_option("experimental"):
+        pytest.skip("the persistent decode step is not part of the product build (build and run with MA_EXPERIMENTAL=1)")
+    if not eng.persist_available():
+        pytest.skip("persistent decode step not available on this device (needs 256 CUs)")
 
 
 def _gen(eng, impl, **kw):
@@ -40,6 +45,7 @@ def _gen(eng, impl, **kw):
 
 
 def test_persistent_step_is_bitwise_the_launch_chain(eng):
+    _need_persist(eng)
     for n in (2, 3, 17, 64):                        # the last step's logits after n - 1 decode steps
         t0, l0, g0 = _gen(eng, 0, max_new_tokens=n, suppress_eos=True)
         t1, l1, g1 = _gen(eng, 1, max_new_tokens=n, suppress_eos=True)
@@ -49,6 +55,7 @@ def test_persistent_step_is_bitwise_the_launch_chain(eng):
 
 
 def test_persistent_generate_400_tokens_token_identical(eng):
+    _need_persist(eng)
     n = int(os.environ.get("MA_TEST_GEN_TOKENS", "400"))
     t0, l0, _ = _gen(eng, 0, max_new_tokens=n, suppress_eos=True)
     t1, l1, _ = _gen(eng, 1, max_new_tokens=n, suppress_eos=True)
@@ -71,6 +78,7 @@ def test_persistent_generate_400_tokens_token_identical(eng):
 
 def test_persistent_falls_back_outside_its_envelope(eng):
     """Sampling and batches of more than one row keep using the launch chain (same results as with decode_impl 0)."""
+    _need_persist(eng)
     u = torch.rand(1, 48, generator=torch.Generator().manual_seed(5))
     eng.set_option("decode_impl", 1)
     try:
@@ -86,6 +94,7 @@ def test_persistent_falls_back_outside_its_envelope(eng):
 
 def test_persistent_step_timing_report(eng):
     """Report-only: decode step (graph replay) of both implementations at three cache lengths + the edge timeline."""
+    _need_persist(eng)
     cfg = eng.cfg
     for L in (300, 3858, cfg.max_seq - 80):
         row = {}
@@ -257,6 +266,8 @@ def test_fc2_inside_the_oproj_fc1_launch_is_bitwise(eng):
 def test_layer_pair_launch_is_bitwise(eng):
     """fuse_layer: the second half of layer l and the first half of layer l + 1 in one launch (csrc/layer_fused.hpp; y2 all-gathered
     inside it).  Same device functions as the two launches it replaces: bit-identical logits and tokens, batch 1 and 2 rows."""
+    if not eng.get_option("experimental"):
+        pytest.skip("the layer-pair launch is not part of the product build (MA_EXPERIMENTAL=1)")
     default = eng.get_option("fuse_layer")
     def run(fuse, prefix, n):
         eng.set_option("fuse_layer", fuse)

@@ -8,7 +8,14 @@ code (tests/golden/make_golden.py, committed fixtures; nothing here reads /root/
     ShapeOPTDecoder.forward trace, within a stated bound, and the same token wherever the reference's top-1/top-2 margin exceeds
     twice that bound; the detokenizer's bins against NoiseResistantDecoder.forward's wherever ITS margin exceeds the bound.
 Bounds (max abs logit error against the fp32 reference): fp32 policy 2e-3; bf16 policy 6e-2 for the decoder (24 layers of bf16 GEMV
-inputs) and 2.5e-2 for the detokenizer logits (measured: 0.036 and 0.015, profiles/r03_reference_anchor.txt)."""
+inputs) and 2.5e-2 for the detokenizer logits (measured: 0.036 and 0.015, profiles/r03_reference_anchor.txt).
+
+  * 350M shape, DIVERSE token streams (full_anchor_hf.npz; round 4): the fixture above walks a constant stream (token 2668 x 65: the default
+    synthetic checkpoint has a fixed point), so every token-dependent path saw one input.  `test_350m_logits_along_the_reference_path`
+    TEACHER-FORCES the engine (ma_sample_cfg.forced_tokens + logits_out) along two reference-produced paths of 257 tokens with
+    >= 32 distinct ids -- a greedy one (weights init="diverse") and one drawn from the reference's own top-k/top-p distribution with
+    stored uniforms (HF-style weights) -- and compares the logits of EVERY step (no early break at a fork), the argmax wherever the
+    reference's margin is decisive, the sampler's draws, the encoder's activations and the detokenizer's bins on those weights."""
 import os
 
 import numpy as np
@@ -117,3 +124,113 @@ def test_350m_logits_and_bins_against_the_reference_modules(policy, golden_dir):
     assert not diff.any() or float(margin[diff].max()) <= 2 * dbound, "a bin differs where the reference's own top-1/top-2 margin is decisive"
     assert int(diff.sum()) <= 0.05 * n_valid
     eng.close()
+
+
+# ---- diverse streams: teacher-forced along the reference's path ---------------------------------------------------------------------------
+# bound = max abs logit error against the reference's fp32 numbers on ALL 257 steps of its path
+PATH_BOUND = {"fp32": 2e-3, "bf16": 8e-2}
+
+
+@pytest.mark.parametrize("tag,init", [("dva", "diverse"), ("hfa", "hf")])
+@pytest.mark.parametrize("policy", ["bf16", "fp32"])
+def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
+    from meshanything_amd.engine import Engine
+    a = dict(np.load(os.path.join(golden_dir, "full_anchor_hf.npz")))
+    d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=1)
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=init)
+    x = torch.from_numpy(d["mouse_norm"])[None].cuda()
+    lat, prefix = eng.encode(x)                                   # the engine's own encoder: the whole chain is under test
+    rows = a[f"{tag}_rows"]
+    e_lat = max(float(np.abs(lat[0, rows].cpu().numpy() - a[f"{tag}_latents_rows"]).max()), float(np.abs(lat[0, :, :8].cpu().numpy() - a[f"{tag}_latents_cols8"]).max()))
+    e_pre = max(float(np.abs(prefix[0, rows].cpu().numpy() - a[f"{tag}_prefix_rows"]).max()), float(np.abs(prefix[0, :, :8].cpu().numpy() - a[f"{tag}_prefix_cols8"]).max()))
+    ref_tok = a[f"{tag}_tokens"]
+    n = len(ref_tok)
+    assert len(set(ref_tok.tolist())) >= 32, "the anchor stream is not diverse"
+    sampled = int(a[f"{tag}_mode"][0]) == 1
+    forced = torch.from_numpy(ref_tok)[None]
+    u = torch.from_numpy(a[f"{tag}_uniforms"])[None]
+    toks, lengths, logits = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True,
+                                         sampling=sampled, uniforms=u if sampled else None)
+    assert toks.shape == (1, n) and int(lengths[0]) == n
+    lg = logits[0]
+    top_i = torch.from_numpy(a[f"{tag}_top_idx"]).long().cuda()
+    top_v = torch.from_numpy(a[f"{tag}_top_val"]).cuda()
+    cols = torch.from_numpy(a[f"{tag}_cols"]).long().cuda()
+    lcols = torch.from_numpy(a[f"{tag}_logits_cols"]).cuda()
+    margin = torch.from_numpy(a[f"{tag}_margin"]).cuda()
+    err = torch.maximum((lg.gather(1, top_i) - top_v).abs().max(dim=1).values, (lg[:, cols] - lcols).abs().max(dim=1).values)
+    bound = PATH_BOUND[policy]
+    lg2 = lg.clone()
+    lg2[:, 1] = float("-inf")
+    eng_arg = lg2.argmax(dim=1)
+    ref_arg = top_i[:, 0]
+    agree = float((eng_arg == ref_arg).float().mean())
+    decisive = margin > 2 * bound
+    picks = toks[0]
+    draw_equal = float((picks.cpu() == torch.from_numpy(ref_tok)).float().mean())
+    print(f"[{policy}/{tag}] {n} steps along the reference's {'sampled' if sampled else 'greedy'} path ({len(set(ref_tok.tolist()))} distinct ids): max abs logit error "
+          f"{float(err.max()):.5f} (bound {bound}), median {float(err.median()):.5f}; argmax agreement {agree * 100:.2f} % ({int(decisive.sum())} decisive steps, reference "
+          f"margin median {float(margin.median()):.4f}); engine's own {'draws' if sampled else 'picks'} equal the reference's tokens at {draw_equal * 100:.2f} % of the steps; "
+          f"encoder latents err {e_lat:.3e}, prefix err {e_pre:.3e}")
+    assert float(err.max()) <= bound, f"step {int(err.argmax())}: logits differ from the reference's by {float(err.max()):.4f}"
+    assert bool((eng_arg[decisive] == ref_arg[decisive]).all()), "argmax differs from the reference's at a decisive margin"
+    if not sampled:
+        assert torch.equal(picks, eng_arg), "the pick kernel's token is not the argmax of the logits it returned"
+        assert agree >= (0.999 if policy == "fp32" else 0.80)
+    else:
+        # the sampler on the reference's own context, with the reference's uniforms, against transformers' warpers: fp32 may differ where
+        # a CDF edge or the top-p cut sits within rounding of the uniform; bf16 logits move the edges by a few 1e-2
+        assert draw_equal >= (0.97 if policy == "fp32" else 0.55), draw_equal
+        assert int(picks.min()) >= 0 and not bool((picks == 1).any())
+    assert e_lat < (1e-5 if policy == "fp32" else 5e-2) and e_pre < (1e-4 if policy == "fp32" else 2e-1)
+    # detokenizer on these weights: bins against the reference's wherever ITS margin is decisive
+    full = dict(np.load(os.path.join(golden_dir, "full.npz")))
+    ids = torch.from_numpy(full["full_detok_ids"]).cuda()
+    coords = eng.detokenize(ids, lat).cpu()
+    valid = torch.from_numpy(a[f"{tag}_detok_valid"])
+    assert torch.equal(~torch.isnan(coords[0, :, 0, 0]), valid)
+    bins = torch.round((coords[0].reshape(-1, 9) + 0.5) * cfg.discrete_num).long()
+    ref_bins = torch.from_numpy(a[f"{tag}_detok_bins"]).long()
+    dmargin = torch.from_numpy(a[f"{tag}_detok_margin"])
+    dbound = {"fp32": 2e-3, "bf16": 2.5e-2}[policy]
+    diff = (bins != ref_bins) & valid[:, None]
+    print(f"[{policy}/{tag}] detokenizer: {int(diff.sum())} of {int(valid.sum()) * 9} bins differ; largest reference margin among them "
+          f"{float(dmargin[diff].max()) if diff.any() else 0.0:.4f} (bound {2 * dbound})")
+    assert not diff.any() or float(dmargin[diff].max()) <= 2 * dbound
+    eng.close()
+
+
+def test_forced_tokens_walk_the_given_stream_tiny():
+    """ma_sample_cfg.forced_tokens / logits_out on the tiny shape, every decode path (batch 1 chain, rows in the grid, matrix-core batch):
+    forcing the engine's OWN greedy stream reproduces it and its logits; forcing another stream reports, at every step, the argmax of
+    the oracle's teacher-forced distribution for that stream."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle
+    for policy, B in (("fp32", 1), ("fp32", 3), ("bf16", 1), ("bf16", 4)):
+        cfg = MAConfig.tiny(dtype=POLICIES[policy], max_batch=4)
+        sd = synthetic_state_dict(cfg)
+        eng = Engine(cfg)
+        eng.load_weights(sd.items())
+        ora = Oracle(cfg, sd, policy, device=oracle_device())
+        g = torch.Generator().manual_seed(17 + B)
+        prefix = torch.randn(B, cfg.cond_length, cfg.hidden, generator=g) * 0.7
+        n = cfg.max_new_tokens
+        free, _, lg_free = eng.generate(prefix.cuda(), suppress_eos=True, return_logits=True)
+        again, _, lg_again = eng.generate(prefix.cuda(), suppress_eos=True, forced_tokens=free, return_logits=True)
+        assert torch.equal(free, again) and torch.equal(lg_free, lg_again), "forcing the engine's own stream changed it"
+        other = torch.randint(3, cfg.vocab, (B, n), generator=g)
+        other[:, 0] = 0
+        picks, lengths, lg = eng.generate(prefix.cuda(), suppress_eos=True, forced_tokens=other, return_logits=True)
+        assert picks.shape == (B, n) and (lengths == n).all()
+        tol = {"fp32": 2e-4, "bf16": 3e-2}[policy]
+        for b in range(B):
+            ref = ora.teacher_forced_logits(prefix[b:b + 1], other[b])[:n]
+            e = float((lg[b].cpu() - ref).abs().max())
+            assert e < tol, (policy, B, b, e)
+            ref2 = ref.clone(); ref2[:, 1] = float("-inf")
+            top2 = torch.topk(ref2, 2, dim=-1)
+            clear = (top2.values[:, 0] - top2.values[:, 1]) > 2 * tol
+            assert torch.equal(picks[b].cpu()[clear], top2.indices[:, 0][clear]), (policy, B, b)
+        eng.close()

@@ -63,3 +63,49 @@ def test_oracle_matches_the_350m_reference_anchor(golden_dir, state_dicts):
     valid = torch.from_numpy(a["anchor_detok_valid"])
     assert torch.equal(ti[..., 0][valid], torch.from_numpy(a["anchor_detok_bins"]).long()[valid])
     assert float(((tv[..., 0] - tv[..., 1])[valid] - torch.from_numpy(a["anchor_detok_margin"])[valid]).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("tag,init", [("dva", "diverse"), ("hfa", "hf")])
+def test_oracle_matches_the_diverse_350m_anchors(tag, init, golden_dir, state_dicts):
+    """full_anchor_hf.npz (round 4): 257 steps along a reference-produced path with >= 32 distinct token ids -- greedy on the
+    init="diverse" weights, drawn from the reference's own top-k/top-p distribution (transformers' warpers, stored uniforms) on the
+    HF-style ones.  The oracle, teacher-forced along the stored tokens, must reproduce the reference's logits at EVERY step, its argmax
+    wherever the margin is above rounding, the warpers' draw, the perceiver's activations and the detokenizer's bins."""
+    a = dict(np.load(os.path.join(golden_dir, "full_anchor_hf.npz")))
+    d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
+    cfg = MAConfig.full()
+    o = Oracle(cfg, state_dicts(cfg, init=init), "fp32")
+    x = torch.from_numpy(d["mouse_norm"])[None]
+    lat = o.encode_latents(x)
+    prefix = o.process_point_feature(lat)
+    rows = a[f"{tag}_rows"]
+    assert float(np.abs(lat[0, rows].numpy() - a[f"{tag}_latents_rows"]).max()) < 1e-5
+    assert float(np.abs(prefix[0, rows].numpy() - a[f"{tag}_prefix_rows"]).max()) < 5e-5
+    toks = torch.from_numpy(a[f"{tag}_tokens"])
+    n = toks.shape[0]
+    assert len(set(toks.tolist())) >= 32
+    lg = o.teacher_forced_logits(prefix, toks)[:n].clone()
+    lg[:, 1] = float("-inf")
+    top_i = torch.from_numpy(a[f"{tag}_top_idx"]).long()
+    err = max(float((lg.gather(1, top_i) - torch.from_numpy(a[f"{tag}_top_val"])).abs().max()),
+              float((lg[:, torch.from_numpy(a[f"{tag}_cols"]).long()] - torch.from_numpy(a[f"{tag}_logits_cols"])).abs().max()))
+    assert err < 5e-4, err
+    margin = torch.from_numpy(a[f"{tag}_margin"])
+    clear = margin > 1e-3
+    assert torch.equal(lg.argmax(dim=1)[clear], top_i[:, 0][clear])
+    if int(a[f"{tag}_mode"][0]) == 1:              # the oracle's restated warpers + inverse-CDF draw against transformers' own, at the 350M vocabulary
+        same = 0
+        for j in range(n):
+            kept, probs = Oracle.topk_topp_filter(lg[j])
+            assert abs(len(kept) - int(a[f"{tag}_kept"][j])) <= 1          # a cumulative mass within rounding of the cut may fall either side
+            same += int(Oracle.sample_from(kept, probs, float(a[f"{tag}_uniforms"][j])) == int(toks[j]))
+        assert same >= n - 3, same
+    else:
+        assert torch.equal(lg.argmax(dim=1)[clear], toks[clear])
+    ids = torch.from_numpy(dict(np.load(os.path.join(golden_dir, "full.npz")))["full_detok_ids"])
+    _, dl = o.detokenize(ids, o.get_codes(ids), lat, return_logits=True)
+    tv, ti = torch.topk(dl[0], 2, dim=-1)
+    valid = torch.from_numpy(a[f"{tag}_detok_valid"])
+    dm = torch.from_numpy(a[f"{tag}_detok_margin"])
+    ok = valid[:, None] & (dm > 1e-3)
+    assert torch.equal(ti[..., 0][ok], torch.from_numpy(a[f"{tag}_detok_bins"]).long()[ok])
