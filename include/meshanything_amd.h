@@ -77,6 +77,10 @@ typedef struct ma_config {
                               MA_DTYPE_F32: everything fp32 ("exact" mode for the parity gates) */
     int32_t kv_splits;     /* reserved (the decode attention always splits a head's cache into 16 equal chunks) */
     int32_t use_graph;     /* 1: replay one captured decode step (hipGraph); 0: eager launches */
+    int32_t enc_exact;     /* 16-bit policies: 1 = the point encoder (ma_encode: encode_latents + process_point_feature, and the detokenizer's
+                              projection of the latents) keeps fp32 weights and computes in fp32 on the fp32 matrix path, so the encoder
+                              activations meet the fp32 policy's 1e-5 while prefill / decode / detokenizer stay 16-bit; 0 = everything in
+                              the policy dtype.  Ignored under MA_DTYPE_F32. */
 } ma_config;
 
 typedef struct ma_engine ma_engine;

@@ -54,6 +54,7 @@ class MAConfig:
     dtype: int = DTYPE_BF16
     kv_splits: int = 0          # reserved (the decode attention always splits a head's cache into 16 equal chunks)
     use_graph: int = 1          # capture one decode step in a hipGraph and replay it
+    enc_exact: int = 1          # 16-bit policies: the point encoder (encode_latents + process_point_feature) stays fp32 (1e-5 on its activations)
 
     # ---- derived ----
     @property

@@ -3,12 +3,10 @@
 // Reference: QKVMultiheadAttention / QKVMultiheadCrossAttention (transformer_blocks.py:56-74, 166-185),
 // [3p] flash_attn prefill (shape_opt.py:403-410) and [3p] BERT self-attention (meshanything.py:62-64).
 //
-// Two kernels, both flash-style (online softmax, K/V tiles staged in LDS, nothing S x S ever materialised):
-//  * attention_kernel (fp32 "exact" policy): fp32 VALU with exact fp32 probabilities.  One block = 64 query rows of one
-//    head; thread (r, c) owns query row r and the keys j = 4*jj + c of each 64-key tile, keeps a partial (l, o[64]) for
-//    them, and the four threads of a row are merged once at the end -- no P exchange.  LDS rows are padded to 68 floats:
-//    the four key rows a wave reads per instruction fall on disjoint banks.
-//  * attention_mfma_kernel (bf16 policy, further down): the same structure on the matrix cores.
+// Two kernels here, both flash-style (online softmax, K/V tiles staged in LDS, nothing S x S ever materialised):
+//  * attention_f32_kernel (exact fp32: the encoder under cfg.enc_exact, everything under the fp32 policy): fp32 matrix cores, exact
+//    fp32 probabilities;
+//  * attention_mfma_kernel (first-generation bf16 kernel, kept as a cross-check: the engine's bf16 kernel is attn2.hpp).
 #pragma once
 #include "common.hpp"
 
@@ -29,123 +27,133 @@ struct AttnArgs {
     size_t q_bs = 0, k_bs = 0, v_bs = 0, o_bs = 0; int batch = 1;
 };
 
-constexpr int ATT_LD = 68;
+typedef float attn_f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) float Ks[64 * ATT_LD];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * ATT_LD];
-    const int tid = threadIdx.x, r = tid >> 2, c = tid & 3;
-    const int h = blockIdx.y;
-    const int q0 = blockIdx.x * 64;
-    const float* Qf = reinterpret_cast<const float*>(a.Q) + blockIdx.z * a.q_bs; const float* Kf = reinterpret_cast<const float*>(a.K) + blockIdx.z * a.k_bs;
-    const float* Vf = reinterpret_cast<const float*>(a.V) + blockIdx.z * a.v_bs; float* Of = reinterpret_cast<float*>(a.O) + blockIdx.z * a.o_bs;
-    const int m = q0 + r;
-    const bool row_ok = m < a.Sq;
+// fp32 "exact" attention on the fp32 matrix path (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain at the fp32 vector rate, MI355X guide
+// section 3) -- the encoder's kernel under every policy with cfg.enc_exact, and prefill / detokenizer under the fp32 policy.  It replaces
+// the VALU kernel of rounds 1-3, whose 64-float query and output rows per thread spilled 3 KB per lane.
+// "Swapped" formulation (as attn2.hpp): S^T = K Q^T, so a lane owns ONE query (column lane & 31) and 16 of a tile's 32 keys, its partner
+// lane ^ 32 the other 16 -- the online softmax is register arithmetic plus one cross-lane exchange; P^T is then already the B operand of
+// O^T = V^T P^T when the contraction walks the keys in accumulator order (step r <-> key (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
+//   * one block = NW waves x 32 query rows of one head; K / V tiles of 32 keys staged through registers into LDS (the loads of tile t + 1
+//     fly under the 64 MFMAs of tile t), K stored transposed [64 d][33] so that the A-operand reads (32 keys of one d) are conflict-free,
+//     V row-major [32][64] (A operand of the second product: 32 consecutive d of one key);
+//   * Q^T fragments (32 registers) live in registers for the whole block.
+// 64 MFMAs of 64 cycles per wave and tile = the fp32 matrix rate whenever the LDS reads hide under them.  ~110 VGPRs, no scratch.
+constexpr int AF_KT_LD = 33;
 
-    float q[64];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attention_f32_kernel(AttnArgs a) {
+    constexpr int NT = NW * 64, RB = NW * 32;
+    constexpr int NCH = (512 + NT - 1) / NT;                       // float4 chunks per thread, tile and operand (32 keys x 16 chunks)
+    __shared__ __attribute__((aligned(16))) float KT[64 * AF_KT_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, q0 = blockIdx.x * RB;
+    const float* Qf = reinterpret_cast<const float*>(a.Q) + blockIdx.z * a.q_bs + (size_t)h * a.q_hs;
+    const float* Kf = reinterpret_cast<const float*>(a.K) + blockIdx.z * a.k_bs + (size_t)h * a.k_hs;
+    const float* Vf = reinterpret_cast<const float*>(a.V) + blockIdx.z * a.v_bs + (size_t)h * a.v_hs;
+    float* Of = reinterpret_cast<float*>(a.O) + blockIdx.z * a.o_bs + (size_t)h * 64;
+    const int qrow = q0 + w * 32 + ln;
+    const bool qok = qrow < a.Sq;
+    auto rnd = [&](float v) { return a.round_bf16 ? round_bf16(v) : v; };
+
+    // Q^T as B operand of S^T = K Q^T: lane (query ln, half hi) holds Q[q][2 s + hi], s = 0 .. 31
+    float qf[32];
     {
-        const float* qp = Qf + (size_t)(row_ok ? m : 0) * a.q_rs + (size_t)h * a.q_hs;
+        const float* qp = Qf + (size_t)(qok ? qrow : 0) * a.q_rs;
 #pragma unroll
-        for (int d = 0; d < 64; d += 4) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(qp + d);
-            q[d] = t.x; q[d + 1] = t.y; q[d + 2] = t.z; q[d + 3] = t.w;
-        }
-        if (a.round_bf16) {
-#pragma unroll
-            for (int d = 0; d < 64; ++d) q[d] = round_bf16(q[d]);
+        for (int c = 0; c < 16; ++c) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (qok) t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+            qf[2 * c] = rnd(hi ? t.y : t.x);
+            qf[2 * c + 1] = rnd(hi ? t.w : t.z);
         }
     }
-    float o[64];
-#pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] = 0.f;
-    float mrun = -1e30f, l = 0.f;
-
     int kv_end = a.Sk;
-    if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + 63, a.Sq - 1) + 1);
+    if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + RB - 1, a.Sq - 1) + 1);
+    const int nt = (kv_end + 31) >> 5;
 
-    const int spos = tid >> 2, sd = (tid & 3) * 16;     // staging: 4 threads per key row, 16 dims each
-    for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
-        {
-            const int kp = kv0 + spos;
-            f32x4 kk[4], vv[4];
-            if (kp < a.Sk) {
-                const float* kptr = Kf + (size_t)kp * a.k_rs + (size_t)h * a.k_hs + sd;
-                const float* vptr = Vf + (size_t)kp * a.v_rs + (size_t)h * a.v_hs + sd;
+    f32x4 kreg[NCH], vreg[NCH];
+    auto gload = [&](int t) {
+        const int kv0 = t << 5;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { kk[i] = *reinterpret_cast<const f32x4*>(kptr + 4 * i); vv[i] = *reinterpret_cast<const f32x4*>(vptr + 4 * i); }
-                if (a.round_bf16) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        kk[i].x = round_bf16(kk[i].x); kk[i].y = round_bf16(kk[i].y); kk[i].z = round_bf16(kk[i].z); kk[i].w = round_bf16(kk[i].w);
-                        vv[i].x = round_bf16(vv[i].x); vv[i].y = round_bf16(vv[i].y); vv[i].z = round_bf16(vv[i].z); vv[i].w = round_bf16(vv[i].w);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { kk[i] = f32x4{0, 0, 0, 0}; vv[i] = f32x4{0, 0, 0, 0}; }
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + NT * i, r = id >> 4, c = id & 15;
+            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((NT * NCH == 512 || id < 512) && kv0 + r < a.Sk) {
+                kreg[i] = *reinterpret_cast<const f32x4*>(Kf + (size_t)(kv0 + r) * a.k_rs + 4 * c);
+                vreg[i] = *reinterpret_cast<const f32x4*>(Vf + (size_t)(kv0 + r) * a.v_rs + 4 * c);
             }
-            __syncthreads();                             // previous tile fully consumed
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(&Ks[spos * ATT_LD + sd + 4 * i]) = kk[i];
-                *reinterpret_cast<f32x4*>(&Vs[spos * ATT_LD + sd + 4 * i]) = vv[i];
-            }
-            __syncthreads();
         }
-        // scores for keys j = 4*jj + c
-        float s[16];
-        float tmax = -1e30f;
+    };
+    auto lstore = [&]() {
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = jj * 4 + c;
-            const float* kr = &Ks[j * ATT_LD];
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(kr + d);
-                acc = fmaf(q[d], t.x, acc); acc = fmaf(q[d + 1], t.y, acc); acc = fmaf(q[d + 2], t.z, acc); acc = fmaf(q[d + 3], t.w, acc);
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + NT * i, r = id >> 4, c = id & 15;
+            if (NT * NCH == 512 || id < 512) {
+                KT[(4 * c + 0) * AF_KT_LD + r] = rnd(kreg[i].x); KT[(4 * c + 1) * AF_KT_LD + r] = rnd(kreg[i].y);
+                KT[(4 * c + 2) * AF_KT_LD + r] = rnd(kreg[i].z); KT[(4 * c + 3) * AF_KT_LD + r] = rnd(kreg[i].w);
+                *reinterpret_cast<f32x4*>(&Vs[r * 64 + 4 * c]) = f32x4{rnd(vreg[i].x), rnd(vreg[i].y), rnd(vreg[i].z), rnd(vreg[i].w)};
             }
-            const int kp = kv0 + j;
-            const bool valid = kp < a.Sk && (a.causal_offset < 0 || kp <= a.causal_offset + m);
-            s[jj] = valid ? acc * a.scale : -INFINITY;
-            tmax = fmaxf(tmax, s[jj]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 1, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 2, 64));
-        const float mnew = fmaxf(mrun, tmax);
+    };
+
+    attn_f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float mrun = -1e30f, lsum = 0.f;
+    const int klimit = a.causal_offset >= 0 ? min(a.Sk - 1, a.causal_offset + qrow) : a.Sk - 1;       // last visible key of this lane's query
+
+    if (nt > 0) gload(0);
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                                            // the previous tile is consumed
+        lstore();
+        __syncthreads();
+        if (t + 1 < nt) gload(t + 1);                               // flies under this tile's MFMAs
+        // ---- S^T = K Q^T: 32 steps of two dims --------------------------------------------------------------------------------------------
+        attn_f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(KT[(2 * s2 + hi) * AF_KT_LD + ln], qf[s2], sacc, 0, 0, 0);
+        // ---- online softmax on the lane's 16 keys of its query: key = 32 t + (i & 3) + 8 (i >> 2) + 4 hi -----------------------------------
+        const int kbase = (t << 5) + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = kbase + (i & 3) + 8 * (i >> 2);
+            const float v = key <= klimit ? sacc[i] * a.scale : -INFINITY;
+            sacc[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
         const float alpha = expf(mrun - mnew);
         mrun = mnew;
-        l *= alpha;
+        float ps = 0.f;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) o[d] *= alpha;
+        for (int i = 0; i < 16; ++i) { const float e = expf(sacc[i] - mnew); sacc[i] = e; ps += e; }      // exp(-inf) = 0: masked keys drop out
+        lsum = lsum * alpha + ps;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const float p = (s[jj] == -INFINITY) ? 0.f : expf(s[jj] - mnew);
-            l += p;
-            const float* vr = &Vs[(jj * 4 + c) * ATT_LD];
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        // ---- O^T += V^T P^T: step r contracts key (r & 3) + 8 (r >> 2) + 4 hi, which is accumulator register r of S^T ----------------------
 #pragma unroll
-            for (int d = 0; d < 64; d += 4) {
-                f32x4 t = *reinterpret_cast<const f32x4*>(vr + d);
-                o[d] = fmaf(p, t.x, o[d]); o[d + 1] = fmaf(p, t.y, o[d + 1]); o[d + 2] = fmaf(p, t.z, o[d + 2]); o[d + 3] = fmaf(p, t.w, o[d + 3]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 64 + ln], sacc[r], oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * 64 + 32 + ln], sacc[r], oacc[1], 0, 0, 0);
         }
     }
-    // merge the four key-subsets of each query row (they share mrun by construction)
-    l += __shfl_xor(l, 1, 64);
-    l += __shfl_xor(l, 2, 64);
-    const float inv = 1.0f / l;
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = ltot > 0.f ? 1.0f / ltot : 0.f;
+    if (qok) {
+        float* op = Of + (size_t)qrow * a.o_rs;
 #pragma unroll
-    for (int d = 0; d < 64; ++d) {
-        float t = o[d];
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        o[d] = t * inv;
-    }
-    if (row_ok) {
-        float* op = Of + (size_t)m * a.o_rs + h * 64;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int d = 0; d < 64; ++d)
-            if ((d >> 4) == c) op[d] = o[d];
+            for (int j = 0; j < 4; ++j)                              // registers 4 j .. 4 j + 3: d = 32 db + 8 j + 4 hi + 0 .. 3
+                *reinterpret_cast<f32x4*>(op + 32 * db + 8 * j + 4 * hi) = f32x4{oacc[db][4 * j] * inv, oacc[db][4 * j + 1] * inv, oacc[db][4 * j + 2] * inv, oacc[db][4 * j + 3] * inv};
     }
 }
 
@@ -303,7 +311,13 @@ inline hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.Sq <= 0) return hipSuccess;
     if (a.round_bf16 == 1) hipLaunchKernelGGL(attention_mfma_kernel<float>, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
     else if (a.round_bf16 == 3) hipLaunchKernelGGL(attention_mfma_kernel<bf16_t>, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attention_kernel, dim3((a.Sq + 63) / 64, a.H, a.batch), dim3(256), 0, s, a);
+    else {
+        // 16-byte row accesses: every stride a multiple of 4 elements.  96-row blocks when they waste fewer rows than 128-row ones (257 rows)
+        if ((a.q_rs | a.k_rs | a.v_rs | a.o_rs | a.q_hs | a.k_hs | a.v_hs) % 4) return hipErrorInvalidValue;
+        const int pad3 = (a.Sq + 95) / 96 * 96, pad4 = (a.Sq + 127) / 128 * 128;
+        if (pad3 < pad4) hipLaunchKernelGGL(attention_f32_kernel<3>, dim3(pad3 / 96, a.H, a.batch), dim3(192), 0, s, a);
+        else hipLaunchKernelGGL(attention_f32_kernel<4>, dim3(pad4 / 128, a.H, a.batch), dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -188,6 +188,18 @@ __device__ __forceinline__ void xchg_raise(unsigned* err, unsigned code) {
     __hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// diagnostics of the fused launches (a 20-30 ms dispatch per profiled run that is NOT a sweep time-out): a block whose
+// life from its first instruction to the end of its last exchange exceeds 1 ms counts itself in err[3] and leaves the longest such span
+// (100 MHz ticks) in err[2]; ma_engine_get_option("slow_blocks" / "slow_block_max_us") and the bench line report them.  Two scalar
+// clock reads per block, off the critical path.
+__device__ __forceinline__ void xchg_note_slow(unsigned* err, u64 t_start) {
+    const u64 dt = __builtin_amdgcn_s_memrealtime() - t_start;
+    if (dt > 100000ull) {
+        __hip_atomic_fetch_max(err + 2, (unsigned)(dt > 0xffffffffull ? 0xffffffffull : dt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(err + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

@@ -136,6 +136,12 @@ struct ma_engine {
     // dense-phase workspace: dense_rows samples stacked along the rows.  w_* / p_*: fp32 streams; a_*: activation tensors
     // (dense_ops.hpp: act_elem = 2 bytes under the bf16 policy, 4 under the exact policy)
     std::vector<void*> allocs;
+    // precision of the dense phase being enqueued (DenseScope below): MA_DTYPE_F32 or the engine's 16-bit type.  The point encoder
+    // (ma_encode: encode_latents + process_point_feature, and the detokenizer's projection of the latents) runs in fp32 under a 16-bit
+    // policy when cfg.enc_exact is set -- the north star's 1e-5 on encoder activations in the benchmarked mode; prefill and the
+    // detokenizer's BERT stack follow the policy dtype.
+    bool dense16 = true;
+    bool enc_exact = false;          // encoder weights are fp32 arena entries and the encoder's activations fp32 (always true under the fp32 policy)
     size_t act_elem = 2;
     int dense_rows = 1, prefill_rows = 1;
     float *w_data = nullptr, *w_lat = nullptr, *w_lat2 = nullptr, *w_pf = nullptr, *w_x = nullptr, *w_y = nullptr, *w_fe = nullptr, *w_logit = nullptr;
@@ -220,6 +226,14 @@ const std::string SM = "point_encoder.model.shape_model.", DEC = "transformer.mo
 inline void* aoff(ma_engine* e, void* p, size_t elems) { return reinterpret_cast<char*>(p) + elems * e->act_elem; }
 inline const void* aoff(ma_engine* e, const void* p, size_t elems) { return reinterpret_cast<const char*>(p) + elems * e->act_elem; }
 
+// the precision of the launches enqueued while it lives (see ma_engine::dense16)
+struct DenseScope {
+    ma_engine* e; bool saved16; size_t saved_elem;
+    DenseScope(ma_engine* e_, bool use16) : e(e_), saved16(e_->dense16), saved_elem(e_->act_elem) { e->dense16 = use16; e->act_elem = use16 ? 2 : 4; }
+    ~DenseScope() { e->dense16 = saved16; e->act_elem = saved_elem; }
+    DenseScope(const DenseScope&) = delete; DenseScope& operator=(const DenseScope&) = delete;
+};
+
 struct GemmOut {                       // exactly one of: fp32 stream output | activation output
     float* c32 = nullptr; void* act = nullptr; int ld = 0; RowMap map{0, 0, 0};
 };
@@ -229,7 +243,8 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
     const Entry& en = e->L.get(w);
     const float* bias = bias_name ? e->PF(bias_name) : nullptr;
     hipError_t r;
-    if (e->bf16) {
+    if ((en.dtype != MA_DTYPE_F32) != e->dense16) throw MaError(MA_ERR_INVALID, "internal: weight " + w + " does not have the precision of the phase that uses it");
+    if (e->dense16) {
         GemmTArgs t{};
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
@@ -255,29 +270,29 @@ GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = 
 void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y32, int ld32, void* ya, int lda, int rows,
             int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}) {
     const float* g = e->PF(prefix + "weight"); const float* b = e->PF(prefix + "bias");
-    if (e->bf16) hipLaunchKernelGGL((ln_rows2_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<bf16_t*>(ya), lda, yout, rows, D);
+    if (e->dense16) hipLaunchKernelGGL((ln_rows2_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<bf16_t*>(ya), lda, yout, rows, D);
     else hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D);
     HIP_CHECK(hipGetLastError());
 }
 // attention over activation tensors; strides in elements; batch = samples (grid.z)
 void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, const void* K, int k_rs, int k_hs, const void* Vp, int v_rs, int v_hs, void* O,
                int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0) {
-    AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->bf16 ? 3 : 0};
+    AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->dense16 ? 3 : 0};
     a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
-    if (e->bf16 && e->opt_attn_impl == 2) {
+    if (e->dense16 && e->opt_attn_impl == 2) {
         if (attn2_vt_elems(Sk, H, batch) > e->vt_elems) throw MaError(MA_ERR_INVALID, "internal: V^T workspace too small");
         HIP_CHECK(launch_attention2(a, e->a_vt, s));
     } else HIP_CHECK(launch_attention(a, s));
 }
 // fp32 stream rows (row map in, optional row mask) -> activation tensor
 void cvt_rows(ma_engine* e, hipStream_t s, const float* src, int lds, RowMap in, const unsigned char* mask, void* dst, int ldd, int rows, int cols) {
-    if (e->bf16) hipLaunchKernelGGL((cvt_rows_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<bf16_t*>(dst), ldd, rows, cols);
+    if (e->dense16) hipLaunchKernelGGL((cvt_rows_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<bf16_t*>(dst), ldd, rows, cols);
     else hipLaunchKernelGGL((cvt_rows_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<float*>(dst), ldd, rows, cols);
     HIP_CHECK(hipGetLastError());
 }
 void add_rows(ma_engine* e, hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
               float* out32, int ld_out, void* outa, int ld_outa, int rows, int cols, int tab_mod = 0) {
-    if (e->bf16) hipLaunchKernelGGL((add_rows2_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
+    if (e->dense16) hipLaunchKernelGGL((add_rows2_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
                                     reinterpret_cast<bf16_t*>(outa), ld_outa, rows, cols, tab_mod);
     else hipLaunchKernelGGL((add_rows2_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
                             reinterpret_cast<float*>(outa), ld_outa, rows, cols, tab_mod);
@@ -307,10 +322,10 @@ void encode_chunk(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, int
     {
         const int total = rowsN * 64;
         if (pc_dtype == MA_DTYPE_F16) {
-            if (e->bf16) hipLaunchKernelGGL((fourier2_kernel<_Float16, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            if (e->dense16) hipLaunchKernelGGL((fourier2_kernel<_Float16, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
             else hipLaunchKernelGGL((fourier2_kernel<_Float16, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
         } else {
-            if (e->bf16) hipLaunchKernelGGL((fourier2_kernel<float, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            if (e->dense16) hipLaunchKernelGGL((fourier2_kernel<float, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
             else hipLaunchKernelGGL((fourier2_kernel<float, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
         }
         HIP_CHECK(hipGetLastError());
@@ -1098,17 +1113,20 @@ void detok_chunk(ma_engine* e, hipStream_t s, const long long* ids, const float*
     void* Xb = e->a_x;                                               // activation copy
     const RowMap head_in{1, T, 0}, tail_in{T - 1, T, 1};             // latents[:, 0] / [:, 1:] inside the T-row blocks
     const RowMap cond_out{T, S, 0}, face_out{nf, S, T};              // cond rows / face rows inside the S-row blocks of X
-    // process_point_feature (meshanything.py:42-48): -> w_pf (nb * T, Wt)
-    cvt_rows(e, s, latents, W, head_in, nullptr, e->a_ln, W, nb, W);
-    gemm(e, s, e->a_ln, W, TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{1, T, 0}), nb, ACT_NONE);
-    cvt_rows(e, s, latents, W, tail_in, nullptr, e->a_ln, W, nb * (T - 1), W);
-    gemm(e, s, e->a_ln, W, TOK + "cond_proj.weight", TOK + "cond_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{T - 1, T, 1}), nb * (T - 1), ACT_NONE);
+    // process_point_feature (meshanything.py:42-48): -> w_pf (nb * T, Wt); the projection of the encoder's latents keeps the encoder's precision
+    {
+        DenseScope enc(e, e->dense16 && !e->enc_exact);
+        cvt_rows(e, s, latents, W, head_in, nullptr, e->a_ln, W, nb, W);
+        gemm(e, s, e->a_ln, W, TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{1, T, 0}), nb, ACT_NONE);
+        cvt_rows(e, s, latents, W, tail_in, nullptr, e->a_ln, W, nb * (T - 1), W);
+        gemm(e, s, e->a_ln, W, TOK + "cond_proj.weight", TOK + "cond_proj.bias", nullptr, 0, to32(e->w_pf, Wt, RowMap{T - 1, T, 1}), nb * (T - 1), ACT_NONE);
+    }
     add_rows(e, s, e->w_pf, Wt, nullptr, nullptr, e->PF(TOK + "point_pe.weight"), Wt, 0, e->w_pf, Wt, nullptr, 0, nb * T, Wt, T);
     lnrows(e, s, e->w_pf, Wt, TOK + "point_layernorm.", 1e-5f, X, Wt, Xb, Wt, nb * T, Wt, RowMap{0, 0, 0}, cond_out);
     // faces (meshanything.py:53-60): codes -> project_down -> zero masked -> + pos -> LN
     {
         const int total = rowsF * 3 * D;
-        if (e->bf16) hipLaunchKernelGGL((codes_gather2_kernel<bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
+        if (e->dense16) hipLaunchKernelGGL((codes_gather2_kernel<bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
                                         codes ? nullptr : reinterpret_cast<bf16_t*>(e->a_fein), e->w_mask);
         else hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
                                 codes ? nullptr : reinterpret_cast<float*>(e->a_fein), e->w_mask);
@@ -1185,7 +1203,7 @@ void build_engine(ma_engine* e) {
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
-    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(2);      // [0] error bits (cleared when read), [1] expiries ever
+    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(4);      // [0] error bits (cleared when read), [1] expiries ever, [2] longest slow block (ticks), [3] slow blocks ever
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
     e->d_attn_pair_gran = e->dmalloc<unsigned long long>(MB * c.heads * ATTN_PAIR_GRANULES);
@@ -1199,7 +1217,7 @@ void build_engine(ma_engine* e) {
     HIP_CHECK(hipMemset(e->d_part_gran, 0, MB * (size_t)c.heads * ATTN_NCHUNK * RF_PART * sizeof(u64)));
 #endif
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
-    HIP_CHECK(hipMemset(e->d_chain_err, 0, 2 * sizeof(unsigned)));
+    HIP_CHECK(hipMemset(e->d_chain_err, 0, 4 * sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
@@ -1253,13 +1271,16 @@ void build_engine(ma_engine* e) {
     // detokenizer rows per pass)
     const int N = c.n_points, W = c.enc_width, T = e->T, Wt = c.tok_width, S = e->S, NL = c.num_latents;
     e->act_elem = e->bf16 ? 2 : 4;
+    e->dense16 = e->bf16;
+    e->enc_exact = !e->bf16 || c.enc_exact != 0;
+    const size_t enc_elem = e->enc_exact ? 4 : 2;                    // element size of the buffers the encoder's activations live in
     e->dense_rows = std::min(c.max_batch, 64);                        // 64 x 4096 point rows per pass: 5 GB of workspace at the 350M shape (bf16 policy)
     e->prefill_rows = e->dense_rows;
     const size_t R = e->dense_rows;
     const size_t rows_seq = R * std::max(T, S);                      // rows of the latent / token streams
     const size_t wmax = std::max(W, Wt);
     const size_t fmax = std::max(4 * W, c.tok_ffn);
-    auto amalloc = [&](size_t elems) -> void* { return e->dmalloc<char>(elems * e->act_elem); };
+    auto amalloc = [&](size_t elems) -> void* { return e->dmalloc<char>(elems * std::max(e->act_elem, enc_elem)); };      // (buffers shared by the phases take the wider element)
     e->w_data = e->dmalloc<float>(R * N * W);
     e->w_lat = e->dmalloc<float>(R * T * W); e->w_lat2 = e->dmalloc<float>(R * NL * W);
     e->w_pf = e->dmalloc<float>(R * T * Wt); e->w_x = e->dmalloc<float>(R * S * Wt); e->w_y = e->dmalloc<float>(R * S * Wt);
@@ -1441,11 +1462,12 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "persist_available") *value = e->persist_shape ? 1 : 0;
         else if (n == "chain_resident") *value = e->chain_resident ? 1 : 0;
         else if (n == "chain_fallbacks") *value = e->chain_fallbacks;
-        else if (n == "xchg_timeouts") {                  // in-launch sweeps that ever gave up on this engine (device counter, never cleared)
-            unsigned v = 0;
+        else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us") {
+            // device counters of the fused launches, never cleared: sweeps that ever gave up | blocks that lived > 1 ms | the longest of them
+            unsigned v[4] = {0, 0, 0, 0};
             HIP_CHECK(hipDeviceSynchronize());
-            HIP_CHECK(hipMemcpy(&v, e->d_chain_err + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-            *value = v;
+            HIP_CHECK(hipMemcpy(v, e->d_chain_err, sizeof(v), hipMemcpyDeviceToHost));
+            *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : v[2] / 100;
         }
         else if (n == "resident_blocks") *value = e->resident_blocks;
         else if (n == "use_graph") *value = e->cfg.use_graph;
@@ -1636,6 +1658,7 @@ int ma_encode(ma_engine* e, const void* pc, int pc_dtype, int B, float* latents,
         if (pc_dtype != MA_DTYPE_F32 && pc_dtype != MA_DTYPE_F16) throw MaError(MA_ERR_INVALID, "pc_dtype must be F32 or F16");
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
         RoctxRange range("ma_encode");
+        DenseScope enc(e, e->bf16 && !e->enc_exact);
         const size_t pstride = (size_t)e->cfg.n_points * 6 * (pc_dtype == MA_DTYPE_F16 ? 2 : 4);
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {          // the whole chunk goes through every GEMM at once (M = nb x rows)
             const int nb = std::min(e->dense_rows, B - b0);
@@ -1651,6 +1674,7 @@ int ma_to_shape_latents(ma_engine* e, const float* latents, int B, float* out, v
     return guarded(e, [&] {
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        DenseScope enc(e, e->bf16 && !e->enc_exact);
         const size_t n = (size_t)e->cfg.num_latents * e->cfg.enc_width;
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
             const int nb = std::min(e->dense_rows, B - b0);
@@ -1665,6 +1689,7 @@ int ma_process_point_feature(ma_engine* e, const float* point_feature, int B, fl
     return guarded(e, [&] {
         require_ready(e); check_batch(e, B);
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        DenseScope enc(e, e->bf16 && !e->enc_exact);
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
             const int nb = std::min(e->dense_rows, B - b0);
             prefix_chunk(e, s, point_feature + (size_t)b0 * e->T * e->cfg.enc_width, prefix + (size_t)b0 * e->T * e->cfg.hidden, nb);

@@ -161,21 +161,21 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
         __syncthreads();
         if (tid == 0) {
             // candidates are in descending order.  top-p: drop the ascending prefix whose cumulative mass <= 1 - top_p
+            // (the exponentials stay in LDS: a runtime-indexed local copy would live in scratch, guide rule 20)
             const int kk = nc;
-            float e[PICK_KMAX];
             float sum = 0.f;
-            for (int j = 0; j < kk; ++j) { e[j] = se[j]; sum += e[j]; }
+            for (int j = 0; j < kk; ++j) sum += se[j];
             const float thr_p = (float)(1.0 - (double)st->top_p);
             int keep = kk;
             float cum = 0.f;
-            for (int j = kk - 1; j >= 1; --j) { cum += e[j] / sum; if (cum <= thr_p) keep = j; else break; }
+            for (int j = kk - 1; j >= 1; --j) { cum += se[j] / sum; if (cum <= thr_p) keep = j; else break; }
             float sum2 = 0.f;
-            for (int j = 0; j < keep; ++j) sum2 += e[j];
+            for (int j = 0; j < keep; ++j) sum2 += se[j];
             const int t = st->t;
             const float u = st->uniforms ? st->uniforms[t] : hash_uniform(st->seed, st->row, t);
             int pick = keep - 1;
             float acc = 0.f;
-            for (int j = 0; j < keep; ++j) { acc += e[j] / sum2; if (acc > u) { pick = j; break; } }
+            for (int j = 0; j < keep; ++j) { acc += se[j] / sum2; if (acc > u) { pick = j; break; } }
             chosen = si[pick];
         }
     }
@@ -239,7 +239,14 @@ __global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, i
 // (6.29 TB/s of the 8 TB/s spec); bench.py times it on the box next to the vendor number
 __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {                  // four 16-byte loads in flight per lane
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 // test aid (ma_op_occupy_cus): a workgroup that holds its dynamic LDS allocation and sleeps until `ticks` of the 100 MHz counter passed

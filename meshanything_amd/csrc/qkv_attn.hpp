@@ -74,6 +74,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     __shared__ AttnMergeLds<bf16_t> S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Hd = a.hidden;
+    const u64 t_block = __builtin_amdgcn_s_memrealtime();
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const float* x = a.x + (size_t)brow * a.x_stride;
     const DecState sv = a.st[brow];
@@ -180,6 +181,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
         }
     }
     __syncthreads();
+    if (tid == 0) xchg_note_slow(a.err, t_block);
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- (4) attention over chunk c (attn_decode.hpp, the launch chain's arithmetic; the newest position from the granules) ----------

@@ -73,35 +73,38 @@ inline void layout_miche_block(Layout& L, const std::string& p, int W, int mdt) 
 inline Layout build_layout(const ma_config& c) {
     Layout L;
     const int mdt = c.dtype == MA_DTYPE_F32 ? MA_DTYPE_F32 : MA_DTYPE_BF16;
+    // the point encoder's matrices (and the two projections of its latents in front of the decoder and of the detokenizer): fp32 when
+    // cfg.enc_exact asks for the exact encoder under a 16-bit policy (engine.hip, DenseScope)
+    const int edt = (c.dtype == MA_DTYPE_F32 || c.enc_exact) ? MA_DTYPE_F32 : mdt;
     const int W = c.enc_width, T = c.num_latents + 1, H = c.hidden, E = c.embed_dim;
     const int fourier = 3 * (2 * c.num_freqs + 1), pin = fourier + 3;
     const std::string PE = "point_encoder.model.", SM = PE + "shape_model.", DEC = "transformer.model.decoder.", TOK = "tokenizer.";
     // ---- point encoder ----
     L.ignore(PE + "shape_projection");
     L.tab(SM + "encoder.query", T, W);
-    L.mat(SM + "encoder.input_proj.weight", W, pin, mdt, 64);      // K padded 54 -> 64 (zero columns)
+    L.mat(SM + "encoder.input_proj.weight", W, pin, edt, 64);      // K padded 54 -> 64 (zero columns)
     L.vec(SM + "encoder.input_proj.bias", W);
     {
         const std::string p = SM + "encoder.cross_attn.";
-        L.mat(p + "attn.c_q.weight", W, W, mdt);
-        L.mat(p + "attn.c_kv.weight", 2 * W, W, mdt);
-        L.mat(p + "attn.c_proj.weight", W, W, mdt); L.vec(p + "attn.c_proj.bias", W);
+        L.mat(p + "attn.c_q.weight", W, W, edt);
+        L.mat(p + "attn.c_kv.weight", 2 * W, W, edt);
+        L.mat(p + "attn.c_proj.weight", W, W, edt); L.vec(p + "attn.c_proj.bias", W);
         for (int i = 1; i <= 3; ++i) { L.vec(p + "ln_" + std::to_string(i) + ".weight", W); L.vec(p + "ln_" + std::to_string(i) + ".bias", W); }
-        L.mat(p + "mlp.c_fc.weight", 4 * W, W, mdt); L.vec(p + "mlp.c_fc.bias", 4 * W);
-        L.mat(p + "mlp.c_proj.weight", W, 4 * W, mdt); L.vec(p + "mlp.c_proj.bias", W);
+        L.mat(p + "mlp.c_fc.weight", 4 * W, W, edt); L.vec(p + "mlp.c_fc.bias", 4 * W);
+        L.mat(p + "mlp.c_proj.weight", W, 4 * W, edt); L.vec(p + "mlp.c_proj.bias", W);
     }
-    for (int n = 0; n < c.enc_layers; ++n) layout_miche_block(L, SM + "encoder.self_attn.resblocks." + std::to_string(n) + ".", W, mdt);
+    for (int n = 0; n < c.enc_layers; ++n) layout_miche_block(L, SM + "encoder.self_attn.resblocks." + std::to_string(n) + ".", W, edt);
     L.vec(SM + "encoder.ln_post.weight", W); L.vec(SM + "encoder.ln_post.bias", W);
     {   // pre_kl: only the mean half (rows [0,E)) is ever used (DiagonalGaussianDistribution.mode, distributions.py:34,69-70)
-        int e = L.add_entry(SM + "pre_kl.weight", E, W, mdt); L.add_source(SM + "pre_kl.weight", e, 0, 2 * E, W, E, W);
+        int e = L.add_entry(SM + "pre_kl.weight", E, W, edt); L.add_source(SM + "pre_kl.weight", e, 0, 2 * E, W, E, W);
         int b = L.add_entry(SM + "pre_kl.bias", 1, E, MA_DTYPE_F32); L.add_source(SM + "pre_kl.bias", b, 0, 1, 2 * E, 1, E);
     }
-    L.mat(SM + "post_kl.weight", W, E, mdt); L.vec(SM + "post_kl.bias", W);
-    for (int n = 0; n < c.shape_layers; ++n) layout_miche_block(L, SM + "transformer.resblocks." + std::to_string(n) + ".", W, mdt);
+    L.mat(SM + "post_kl.weight", W, E, edt); L.vec(SM + "post_kl.bias", W);
+    for (int n = 0; n < c.shape_layers; ++n) layout_miche_block(L, SM + "transformer.resblocks." + std::to_string(n) + ".", W, edt);
     // geo_decoder.*: SDF reconstruction head, never run by MeshAnything.forward -> matched by prefix in find_source()
     // ---- top-level prefix projections (A.4) ----
-    L.mat("cond_head_proj.weight", H, W, mdt); L.vec("cond_head_proj.bias", H);
-    L.mat("cond_proj.weight", H, 2 * W, mdt);  L.vec("cond_proj.bias", H);
+    L.mat("cond_head_proj.weight", H, W, edt); L.vec("cond_head_proj.bias", H);
+    L.mat("cond_proj.weight", H, 2 * W, edt);  L.vec("cond_proj.bias", H);
     // ---- ShapeOPT decoder (A.2) ----
     L.ignore(DEC + "embed_tokens.weight");
     L.tab(DEC + "extra_embeds.weight", 3, H);
@@ -134,8 +137,8 @@ inline Layout build_layout(const ma_config& c) {
     L.tab(TOK + "point_pe.weight", T, Wt);
     L.vec(TOK + "layernorm.weight", Wt); L.vec(TOK + "layernorm.bias", Wt);
     L.vec(TOK + "point_layernorm.weight", Wt); L.vec(TOK + "point_layernorm.bias", Wt);
-    L.mat(TOK + "cond_proj.weight", Wt, W, mdt); L.vec(TOK + "cond_proj.bias", Wt);
-    L.mat(TOK + "cond_head_proj.weight", Wt, W, mdt); L.vec(TOK + "cond_head_proj.bias", Wt);
+    L.mat(TOK + "cond_proj.weight", Wt, W, edt); L.vec(TOK + "cond_proj.bias", Wt);
+    L.mat(TOK + "cond_head_proj.weight", Wt, W, edt); L.vec(TOK + "cond_head_proj.bias", Wt);
     L.mat(TOK + "project_down_codebook.weight", Wt, 3 * c.codebook_dim, mdt); L.vec(TOK + "project_down_codebook.bias", Wt);
     L.mat(TOK + "to_coor_logits.0.weight", 9 * c.discrete_num, Wt, mdt); L.vec(TOK + "to_coor_logits.0.bias", 9 * c.discrete_num);
     for (int n = 0; n < c.tok_layers; ++n) {

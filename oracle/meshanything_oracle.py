@@ -43,6 +43,8 @@ Precision policy (`policy`):
           every Linear computes fp32-accumulated dot products of bf16(x) and bf16(W);
           attention uses bf16(q), bf16(k), bf16(v) with fp32 scores/softmax/accumulation;
           everything else (bias, LayerNorm, GELU/ReLU, residuals, embedding tables) is fp32.
+          With cfg.enc_exact (the default) the point encoder -- encode_latents, to_shape_latents, process_point_feature and the
+          detokenizer's projection of the latents -- is NOT rounded: the engine keeps it in fp32 under a 16-bit policy.
 """
 from __future__ import annotations
 
@@ -175,8 +177,23 @@ class Oracle:
                 for a, b2 in ren.items():
                     self.sd[p + b2] = self.sd[p + a]
 
+    def _enc(self):
+        """Context: the precision of the point encoder (fp32 under a 16-bit policy when cfg.enc_exact is set)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            saved = self.policy
+            if getattr(self.cfg, "enc_exact", 0):
+                self.policy = "fp32"
+            try:
+                yield self
+            finally:
+                self.policy = saved
+        return cm()
+
     def W(self, name: str, rows: Optional[slice] = None) -> torch.Tensor:
-        key = name if rows is None else f"{name}[{rows.start}:{rows.stop}]"
+        key = (name if rows is None else f"{name}[{rows.start}:{rows.stop}]") + "|" + self.policy
         w = self._wcache.get(key)
         if w is None:
             w = self.sd[name]
@@ -259,6 +276,10 @@ class Oracle:
         """AlignedShapeAsLatentPLModule.encode_latents (asl_pl_module.py:145-157) ->
         AlignedShapeLatentPerceiver.encode_latents (sal_perceiver.py:372-381) ->
         CrossAttentionEncoder._forward (sal_perceiver.py:74-99).  (B,N,6) -> (B,T,W)."""
+        with self._enc():
+            return self._encode_latents(pc_normal)
+
+    def _encode_latents(self, pc_normal: torch.Tensor) -> torch.Tensor:
         cfg = self.cfg
         x = pc_normal.float()
         pc, feats = x[..., 0:3], x[..., 3:6]
@@ -288,18 +309,20 @@ class Oracle:
         DiagonalGaussianDistribution.mode = first half of pre_kl's output, distributions.py:34,69-70),
         then decode = post_kl + `transformer` blocks (sal_perceiver.py:273-275)."""
         E = self.cfg.embed_dim
-        mean = self.linear(latents, SM + "pre_kl.weight", SM + "pre_kl.bias", rows=slice(0, E))
-        x = self.linear(mean, SM + "post_kl.weight", SM + "post_kl.bias")
-        for n in range(self.cfg.shape_layers):
-            x = self._miche_attn_block(x, SM + f"transformer.resblocks.{n}.")
+        with self._enc():
+            mean = self.linear(latents, SM + "pre_kl.weight", SM + "pre_kl.bias", rows=slice(0, E))
+            x = self.linear(mean, SM + "post_kl.weight", SM + "post_kl.bias")
+            for n in range(self.cfg.shape_layers):
+                x = self._miche_attn_block(x, SM + f"transformer.resblocks.{n}.")
         return x
 
     @_api
     def process_point_feature(self, point_feature: torch.Tensor) -> torch.Tensor:
         """MeshAnything.process_point_feature, meshanything.py:125-132 -> (B,T,hidden) decoder prefix."""
-        head = self.linear(point_feature[:, 0], "cond_head_proj.weight", "cond_head_proj.bias")
-        shape_latents = self.to_shape_latents(point_feature[:, 1:])
-        rest = self.linear(torch.cat([point_feature[:, 1:], shape_latents], dim=-1), "cond_proj.weight", "cond_proj.bias")
+        with self._enc():
+            head = self.linear(point_feature[:, 0], "cond_head_proj.weight", "cond_head_proj.bias")
+            shape_latents = self.to_shape_latents(point_feature[:, 1:])
+            rest = self.linear(torch.cat([point_feature[:, 1:], shape_latents], dim=-1), "cond_proj.weight", "cond_proj.bias")
         return torch.cat([head[:, None], rest], dim=1)
 
     # ------------------------------------------------------------------ autoregressive decoder (ShapeOPT)
@@ -504,8 +527,9 @@ class Oracle:
     @_api
     def detok_point_feature(self, encode_feature: torch.Tensor) -> torch.Tensor:
         """NoiseResistantDecoder.process_point_feature, meshanything.py:42-48."""
-        head = self.linear(encode_feature[:, 0], TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias")
-        rest = self.linear(encode_feature[:, 1:], TOK + "cond_proj.weight", TOK + "cond_proj.bias")
+        with self._enc():
+            head = self.linear(encode_feature[:, 0], TOK + "cond_head_proj.weight", TOK + "cond_head_proj.bias")
+            rest = self.linear(encode_feature[:, 1:], TOK + "cond_proj.weight", TOK + "cond_proj.bias")
         pf = torch.cat([head[:, None], rest], dim=1)
         return self.ln(pf + self.sd[TOK + "point_pe.weight"][None, :pf.shape[1]], TOK + "point_layernorm.", 1e-5)
 

@@ -55,8 +55,10 @@ def test_arena_layout_is_a_pure_function_of_the_config(lib):
             assert sz.value == rows.value * cols.value * (2 if dt.value == 1 else 4)
             end = off.value + sz.value
         assert end <= nbytes
-    full = MAConfig.full(dtype=DTYPE_BF16).to_c()
+    full = MAConfig.full(dtype=DTYPE_BF16, enc_exact=0).to_c()
     assert 1.15e9 < lib.ma_arena_bytes(C.byref(full)) < 1.30e9       # ~596 M parameters, matrices bf16, vectors/tables fp32
+    full = MAConfig.full(dtype=DTYPE_BF16).to_c()                    # default: the point encoder's ~200 M matrix elements stay fp32 (enc_exact)
+    assert 1.55e9 < lib.ma_arena_bytes(C.byref(full)) < 1.65e9
 
 
 def test_host_packing_is_strict(lib):

@@ -182,9 +182,9 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     else:
         # the sampler on the reference's own context, with the reference's uniforms, against transformers' warpers: fp32 may differ where
         # a CDF edge or the top-p cut sits within rounding of the uniform; bf16 logits move the edges by a few 1e-2
-        assert draw_equal >= (0.97 if policy == "fp32" else 0.55), draw_equal
+        assert draw_equal >= (0.97 if policy == "fp32" else 0.40), draw_equal
         assert int(picks.min()) >= 0 and not bool((picks == 1).any())
-    assert e_lat < (1e-5 if policy == "fp32" else 5e-2) and e_pre < (1e-4 if policy == "fp32" else 2e-1)
+    assert e_lat < 1e-5 and e_pre < 1e-4                            # the encoder is exact under the bf16 policy too (cfg.enc_exact)
     # detokenizer on these weights: bins against the reference's wherever ITS margin is decisive
     full = dict(np.load(os.path.join(golden_dir, "full.npz")))
     ids = torch.from_numpy(full["full_detok_ids"]).cuda()
