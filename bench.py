@@ -27,7 +27,7 @@ import torch  # noqa: E402
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F32  # noqa: E402
+from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32  # noqa: E402
 from meshanything_amd.checkpoint import synthetic_state_dict          # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--faces", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=4)
@@ -244,7 +244,7 @@ def main():
 
     from meshanything_amd.engine import Engine
     from meshanything_amd import dp
-    cfg = MAConfig.full(dtype=DTYPE_BF16 if args.dtype == "bf16" else DTYPE_F32, n_max_faces=args.faces, max_batch=args.batch)
+    cfg = MAConfig.full(dtype={"bf16": DTYPE_BF16, "fp16": DTYPE_F16, "fp32": DTYPE_F32}[args.dtype], n_max_faces=args.faces, max_batch=args.batch)
     eng = Engine(cfg, local_rank)
     sd = {}
     t_load = time.time()
@@ -303,7 +303,7 @@ def main():
         enc_err = float(max(np.abs(lat0[gold["full_rows"]] - gold["full_latents_rows"]).max(), np.abs(lat0[:, :8] - gold["full_latents_cols8"]).max()))
 
     if rank == 0:
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 4 if args.dtype == "fp32" else 2
         # ---- per-phase times (one extra pass, HIP events on the current stream) ----
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
@@ -325,7 +325,7 @@ def main():
         prof = eng.profile_decode(mid, args.profile_steps)
         wbytes, _ = gemv_bytes_per_step(cfg, esz)
         kvbytes = args.batch * kv_bytes_per_step(cfg, mid, esz)
-        mfma_path = args.batch >= 4 and args.dtype == "bf16"
+        mfma_path = args.batch >= 4 and args.dtype != "fp32"
         fused_qkv = bool(eng.get_option("fuse_qkv_attn")) and not mfma_path
         fused_o1 = bool(eng.get_option("fuse_oproj_fc1")) and not mfma_path
         fused_f2 = fused_o1 and bool(eng.get_option("fuse_fc2"))
@@ -375,6 +375,7 @@ def main():
         batched = None
         dense = None
         fp32_exact = None
+        fp16_policy = None
         if args.batch == 1 and not args.no_batched_table and args.dtype == "bf16" and world == 1:
             # configs 3-5 in brief: the decode step when 8 / 64 shapes share the weight stream (mid context, graph replay)
             eng.close()
@@ -408,6 +409,22 @@ def main():
             fp32_exact = {"face_tokens_per_s": round(cfg_x.max_new_tokens / t_x, 1), "sec_per_mesh": round(t_x, 3), "meshes_timed": 1,
                           "note": "MA_DTYPE_F32 policy, same cloud and weights, one warm mesh; streams 2x the bytes of the bf16 policy"}
             eng_x.close()
+            # the reference's own arithmetic class (fp16 autocast, main.py:114-118,149): the same mesh under MA_DTYPE_F16 -- same kernels, IEEE half
+            # instead of bf16 in weights / KV / GEMM inputs
+            cfg_h = MAConfig.full(dtype=DTYPE_F16, n_max_faces=args.faces, max_batch=1)
+            eng_h = Engine(cfg_h, local_rank)
+            eng_h.load_weights(sd.items())
+            eng_h.forward(x[:1], suppress_eos=True, max_new_tokens=64)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            oh = eng_h.forward(x[:1], suppress_eos=True)
+            torch.cuda.synchronize()
+            t_h = time.perf_counter() - t1
+            fp16_policy = {"face_tokens_per_s": round(cfg_h.max_new_tokens / t_h, 1), "sec_per_mesh": round(t_h, 3), "meshes_timed": 1,
+                           "tokens_distinct": len(set(oh["tokens"][0].tolist())),
+                           "tokens_equal_to_the_bf16_run": int((oh["tokens"][0].cpu() == out["tokens"][0].cpu()).sum()),
+                           "note": "MA_DTYPE_F16 policy (the reference's fp16-autocast precision class), same cloud and weights, one warm mesh"}
+            eng_h.close()
         total_tokens = world * args.steps * tokens_per_step
         res = {
             "metric": f"face-tokens/sec ({args.faces}-face cap, batch {args.batch} per GPU) + sec/mesh", "value": round(total_tokens / dt, 2), "unit": "face-tokens/s",
@@ -417,7 +434,7 @@ def main():
                        "global_batch": pl["global_batch"], "tokens_per_mesh": cfg.max_new_tokens, "parallelism": pl["parallelism"],
                        "weights": "seeded random init in the reference key layout (no checkpoint available offline), init=diverse: checkpoint.py"},
             "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "dense_phases": dense, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
-            "weights_load_s": round(t_load, 2), "fp32_exact": fp32_exact, "roofline": roofline, "cpu_baseline": cpu,
+            "weights_load_s": round(t_load, 2), "fp32_exact": fp32_exact, "fp16_policy": fp16_policy, "roofline": roofline, "cpu_baseline": cpu,
             "tokens_distinct": tokens_distinct, "encoder_max_abs_err": enc_err, "fused_launch_health": {"timed_region": health, "after_profiling": health_after},
             "measured_peaks": peaks,
         }

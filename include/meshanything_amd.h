@@ -38,7 +38,7 @@ enum {
     MA_ERR_NCCL = -7            /* RCCL call failed / librccl not loadable */
 };
 
-/* element types: engine policy (ma_config.dtype: F32 or BF16) and source-tensor dtypes of ma_tensor_desc */
+/* element types: engine policy (ma_config.dtype) and source-tensor dtypes of ma_tensor_desc */
 enum { MA_DTYPE_F32 = 0, MA_DTYPE_BF16 = 1, MA_DTYPE_F16 = 2 };
 
 /* Shape + policy.  Field order mirrors meshanything_amd/config.py::MAConfig (all int32).
@@ -73,7 +73,8 @@ typedef struct ma_config {
     int32_t discrete_num;  /* 128  */
     /* engine policy */
     int32_t max_batch;     /* largest B accepted by encode/generate/detokenize/forward */
-    int32_t dtype;         /* MA_DTYPE_BF16: bf16 weights + KV, GEMM/attention inputs rounded to bf16, fp32 accumulate;
+    int32_t dtype;         /* MA_DTYPE_BF16: bf16 weights + KV, GEMM/attention inputs rounded to bf16, fp32 accumulate (BASELINE.json's policy);
+                              MA_DTYPE_F16: the same with IEEE half -- the reference's own arithmetic (fp16 autocast, main.py:114-118,149);
                               MA_DTYPE_F32: everything fp32 ("exact" mode for the parity gates) */
     int32_t kv_splits;     /* reserved (the decode attention always splits a head's cache into 16 equal chunks) */
     int32_t use_graph;     /* 1: replay one captured decode step (hipGraph); 0: eager launches */
@@ -274,6 +275,11 @@ MA_API int  ma_op_rows_prologue(int pro, const float *x, int nparts, int B, cons
  * launches -- which need their whole grid resident -- fall back to the five-launch chain instead of failing the request.  Has no
  * reference counterpart (the reference never shares a device between streams). */
 MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, const int32_t *release, void *stream);
+
+/* ---- the 16-bit format (MA_DTYPE_BF16, the default, or MA_DTYPE_F16) of the kernel-level entry points above that carry no dtype argument
+ * (ma_op_gemm_bf16, ma_op_attention mode 4, ma_op_decode_attention_rows, ma_op_gemm_dec*, ma_op_rows_prologue): their "bf16" operands are then
+ * IEEE half.  Per calling thread; parity tests run every 16-bit kernel in both formats.  No reference counterpart. */
+MA_API int  ma_op_set_half_dtype(int dtype);
 
 /* ---- measurement aid: dst[0, bytes) = src[0, bytes) as a 16-byte-per-lane streaming copy (2048 blocks, grid-stride); bytes % 16 == 0.  bench.py
  * times it to report the box's achievable HBM rate next to the 8 TB/s vendor number.  No reference counterpart. */

@@ -38,7 +38,7 @@ def get_args():
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--mc", default=False, action="store_true")
     p.add_argument("--sampling", default=False, action="store_true")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--synthetic_weights", default=False, action="store_true", help="seeded random checkpoint (no released file offline)")
     return p.parse_args()
 

@@ -20,6 +20,7 @@ HEAD_DIM = 64
 # weight / KV-cache precision policies (include/meshanything_amd.h: MA_DTYPE_*)
 DTYPE_F32 = 0   # "exact" mode: fp32 weights, fp32 KV cache, no activation rounding
 DTYPE_BF16 = 1  # bf16 weights + bf16 KV cache; GEMM/attention inputs rounded to bf16, fp32 accumulate
+DTYPE_F16 = 2   # the same with IEEE half: the reference's own arithmetic (fp16 autocast, main.py:114-118,149)
 
 
 @dataclass

@@ -49,8 +49,9 @@ __device__ __forceinline__ int a2_slot(int row, int chunk) { return chunk ^ ((ro
 // two floats -> packed bf16 (round to nearest even; v_cvt_pk_bf16_f32 on gfx950), element 0 in the low half
 typedef float a2_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 a2_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t a2_pack(float lo, float hi_) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(a2_f32x2{lo, hi_}, a2_bf16x2));
+template <typename HT> __device__ __forceinline__ uint32_t a2_pack(float lo, float hi_) {
+    if constexpr (__is_same(HT, f16_t)) return H16<f16_t>::pack2(lo, hi_);
+    else return __builtin_bit_cast(uint32_t, __builtin_convertvector(a2_f32x2{lo, hi_}, a2_bf16x2));
 }
 
 // V (Sk rows x 64 d per head, row stride v_rs, head offset h * v_hs) -> V^T [batch][H][64][skp], zero beyond Sk, the keys of every
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
     }
 }
 
-template <int NW>
+// HT: the 16-bit format of Q / K / V^T / O (bf16_t | f16_t, common.hpp H16)
+template <int NW, typename HT = bf16_t>
 __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
     constexpr int NT = NW * 64, RB = NW * 32, TILE = 64 * 128;         // threads, query rows per block, bytes of one K or V^T tile
     constexpr int NCH = (512 + NT - 1) / NT;                            // 16-byte chunks per thread, tile and operand
@@ -99,14 +101,14 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
     const bool qok = qrow < a.Sq;
 
     // Q^T fragments: B[k = d][n = query]: lane (query ln, k group hi) holds d = 16 s + 8 hi .. + 7 for the four 16-deep steps
-    bf16x8_t qf[4];
+    u32x4 qf[4];
     {
         const bf16_t* qp = Qp + (size_t)(qok ? qrow : 0) * a.q_rs + 8 * hi;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (qok) v = *reinterpret_cast<const u32x4*>(qp + 16 * s);
-            qf[s] = __builtin_bit_cast(bf16x8_t, v);
+            qf[s] = v;
         }
     }
     int kv_end = a.Sk;
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
             const int r = kbk * 32 + ln;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
-                sacc[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kbk], 0, 0, 0);
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(kb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
+                sacc[kbk] = H16<HT>::mfma32(kf, qf[s], sacc[kbk]);
             }
         }
         // ---- online softmax on the lane's 32 keys of its query: key = 64 t + 32 kbk + (i & 3) + 8 (i >> 2) + 4 hi ----------------------
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
         const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         mrun = mnew;
         float ps = 0.f;
-        bf16x8_t pf[4];                                                 // P^T as B fragments: slice s = keys 16 s .. 16 s + 15 of the tile
+        u32x4 pf[4];                                                    // P^T as B fragments: slice s = keys 16 s .. 16 s + 15 of the tile
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             uint32_t w4[4];
@@ -190,9 +192,9 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
                 const float e0 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j] - mnew);        // exp2(-inf) = 0: masked keys drop out
                 const float e1 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j + 1] - mnew);
                 ps += e0 + e1;
-                w4[j] = a2_pack(e0, e1);
+                w4[j] = a2_pack<HT>(e0, e1);
             }
-            pf[s] = __builtin_bit_cast(bf16x8_t, u32x4{w4[0], w4[1], w4[2], w4[3]});
+            pf[s] = u32x4{w4[0], w4[1], w4[2], w4[3]};
         }
         lsum = lsum * alpha + ps;
 #pragma unroll
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
             const int r = db * 32 + ln;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(vb + r * 128 + a2_slot(r, 2 * s + hi) * 16);
+                oacc[db] = H16<HT>::mfma32(vf, pf[s], oacc[db]);
             }
         }
         if (t + 1 < nt) lstore((t + 1) & 1);                            // the other stage: last read during tile t - 1, before the previous barrier
@@ -219,8 +221,8 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                                   // registers 4 j .. 4 j + 3: d = 32 db + 8 j + 4 hi + 0 .. 3
             u32x2 pk;
-            pk.x = a2_pack(oacc[db][4 * j] * inv, oacc[db][4 * j + 1] * inv);
-            pk.y = a2_pack(oacc[db][4 * j + 2] * inv, oacc[db][4 * j + 3] * inv);
+            pk.x = a2_pack<HT>(oacc[db][4 * j] * inv, oacc[db][4 * j + 1] * inv);
+            pk.y = a2_pack<HT>(oacc[db][4 * j + 2] * inv, oacc[db][4 * j + 3] * inv);
             *reinterpret_cast<u32x2*>(patch + ln * 128 + a2_slot(ln, 4 * db + j) * 16 + 8 * hi) = pk;
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the patch is private to the wave: its LDS queue is in order, no barrier needed
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
 inline size_t attn2_vt_elems(int Sk, int H, int batch) { return (size_t)batch * H * 64 * ((Sk + 63) & ~63); }
 
 // V^T packing + attention.  `vt` = workspace of attn2_vt_elems(Sk, H, batch) bf16 elements.
+template <typename HT>
 inline hipError_t launch_attention2(const AttnArgs& a, bf16_t* vt, hipStream_t s) {
     if (a.Sq <= 0 || a.Sk <= 0) return hipSuccess;
     const int skp = (a.Sk + 63) & ~63;
@@ -244,8 +247,8 @@ inline hipError_t launch_attention2(const AttnArgs& a, bf16_t* vt, hipStream_t s
                 a.Sq, a.Sk, skp, a.H, a.scale, a.causal_offset, a.q_bs, a.k_bs, a.o_bs};
     // 96-row blocks when they waste fewer rows than 128-row blocks (257 rows: 288 vs 384)
     const int pad3 = (a.Sq + 95) / 96 * 96, pad4 = (a.Sq + 127) / 128 * 128;
-    if (pad3 < pad4) hipLaunchKernelGGL(attention_mfma2_kernel<3>, dim3(pad3 / 96, a.H, a.batch), dim3(192), 0, s, g);
-    else hipLaunchKernelGGL(attention_mfma2_kernel<4>, dim3(pad4 / 128, a.H, a.batch), dim3(256), 0, s, g);
+    if (pad3 < pad4) hipLaunchKernelGGL((attention_mfma2_kernel<3, HT>), dim3(pad3 / 96, a.H, a.batch), dim3(192), 0, s, g);
+    else hipLaunchKernelGGL((attention_mfma2_kernel<4, HT>), dim3(pad4 / 128, a.H, a.batch), dim3(256), 0, s, g);
     return hipGetLastError();
 }
 

@@ -83,10 +83,7 @@ template <typename KT> struct AttnGeom {
 template <typename KT> __device__ __forceinline__ void attn_unpack(const u32x4& r, float (&f)[16 / sizeof(KT)]) {
     if constexpr (sizeof(KT) == 4) {
         f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
-    } else {
-        f[0] = bf_lo(r.x); f[1] = bf_hi(r.x); f[2] = bf_lo(r.y); f[3] = bf_hi(r.y);
-        f[4] = bf_lo(r.z); f[5] = bf_hi(r.z); f[6] = bf_lo(r.w); f[7] = bf_hi(r.w);
-    }
+    } else unpack8<KT>(r, f);
 }
 // online-softmax state of one position slot (the LPP lanes of a slot hold the same m, l and their own EPL dims of o)
 template <typename KT> struct AttnSlotState { float m, l, o[16 / sizeof(KT)]; };
@@ -230,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     };
     if (round_q) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) qv[e] = round_bf16(qv[e]);
+        for (int e = 0; e < EPL; ++e) qv[e] = H16<KT>::round(qv[e]);
     }
     if (nround > 0) issue(0, kA, vA);
     for (int r = 0; r < nround; r += 2) {
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
     };
     if (round_q) {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) qv[e] = round_bf16(qv[e]);
+        for (int e = 0; e < EPL; ++e) qv[e] = H16<KT>::round(qv[e]);
     }
     if (nround > 0) issue(0, kA, vA);
     for (int r = 0; r < nround; r += 2) {
@@ -434,7 +431,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
             L = fmaf(L2, f2, L * f1);
             O = fmaf(O2, f2, O * f1);
         }
-        out[(size_t)brow * out_stride + h * 64 + lane] = f2bf(O * (1.0f / L));     // position 0 always exists: L > 0
+        out[(size_t)brow * out_stride + h * 64 + lane] = H16<KT>::bits(O * (1.0f / L));     // position 0 always exists: L > 0
     }
 }
 

@@ -43,6 +43,83 @@ __host__ inline float half2float_host(uint16_t h) {
 __device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// fp32 -> IEEE half bits, round-to-nearest-even, overflow -> inf (torch .to(float16)); host side of the weight packer
+__host__ inline uint16_t float2half_host(float f) {
+    union { float f; uint32_t u; } v; v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u, abs = v.u & 0x7fffffffu;
+    if (abs > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                       // NaN
+    if (abs >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                      // >= 65520: rounds to inf
+    if (abs < 0x38800000u) {                                                        // subnormal half (|f| < 2^-14) or zero
+        if (abs < 0x33000000u) return (uint16_t)sign;                               // < 2^-25: rounds to zero
+        const int shift = 126 - (int)(abs >> 23);                                   // 14 .. 24
+        const uint32_t man = (abs & 0x7fffffu) | 0x800000u;
+        uint32_t r = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((abs - 0x38000000u) >> 13);                                        // rebias the exponent, keep 10 mantissa bits
+    const uint32_t rem = abs & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;                          // a mantissa carry moves into the exponent: still right
+    return (uint16_t)(sign | r);
+}
+
+// ---- the engine's two 16-bit formats -------------------------------------------------------------------------------------------
+// Storage is always raw 16-bit words (`bf16_t` pointers: weights, KV cache, activation tensors); the FORMAT is a compile-time tag of the
+// kernels that touch it.  bf16 (MA_DTYPE_BF16: BASELINE.json's policy) and IEEE fp16 (MA_DTYPE_F16: the reference's own arithmetic --
+// Accelerator(mixed_precision="fp16") + autocast, main.py:114-118,149) share every kernel; H16<T> holds what differs: the conversions
+// and the matrix-core instruction.  `f16_t` is the tag (and the element type where a kernel is templated on its weight / cache type).
+struct f16_t { uint16_t v; };
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    static constexpr bool is16 = true;
+    static __device__ __forceinline__ float lo(uint32_t w) { return bf_lo(w); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return bf_hi(w); }
+    static __device__ __forceinline__ float one(uint16_t b) { return bf2f(b); }
+    static __device__ __forceinline__ uint16_t bits(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float round(float f) { return bf2f(f2bf(f)); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+    static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16_t> {
+    static constexpr bool is16 = true;
+    static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+    static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+    static __device__ __forceinline__ float one(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+    static __device__ __forceinline__ uint16_t bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static __device__ __forceinline__ float round(float f) { return (float)(_Float16)f; }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, f16x2_t{(_Float16)a, (_Float16)b}); }
+    static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct H16<float> {       // the fp32 "exact" policy: nothing is rounded
+    static constexpr bool is16 = false;
+    static __device__ __forceinline__ float round(float f) { return f; }
+};
+// eight 16-bit elements (one 16-byte load) -> eight floats
+template <typename HT>
+__device__ __forceinline__ void unpack8(const u32x4& w, float* f) {
+    f[0] = H16<HT>::lo(w.x); f[1] = H16<HT>::hi(w.x); f[2] = H16<HT>::lo(w.y); f[3] = H16<HT>::hi(w.y);
+    f[4] = H16<HT>::lo(w.z); f[5] = H16<HT>::hi(w.z); f[6] = H16<HT>::lo(w.w); f[7] = H16<HT>::hi(w.w);
+}
+// four floats -> four 16-bit elements
+template <typename HT>
+__device__ __forceinline__ u32x2 pack4(const f32x4& v) { u32x2 p; p.x = H16<HT>::pack2(v.x, v.y); p.y = H16<HT>::pack2(v.z, v.w); return p; }
+
 // ---- wave reductions on the DPP path (no LDS crossbar: __shfl_xor lowers to ds_bpermute_b32, ~100 cycles per step
 // and six dependent steps per reduction; a DPP step is one VALU op).  quad_perm xor 1, xor 2, then row_half_mirror and
 // row_mirror leave every lane of a 16-lane row with the row total; the four row totals are fetched with v_readlane.

@@ -12,6 +12,7 @@ namespace ma {
 template <typename T> __device__ __forceinline__ void st_act(T* p, float v);
 template <> __device__ __forceinline__ void st_act<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_act<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void st_act<f16_t>(f16_t* p, float v) { p->v = H16<f16_t>::bits(v); }
 
 // FourierEmbedder.forward (embedder.py:87-105) + normals concat (sal_perceiver.py:87-89), rows = all points of the batch:
 // out[i] = [x(3) | sin(x_d * 2^f) (d-major) | cos(...) | normal(3) | 0-pad to ld]
@@ -73,9 +74,7 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
             if (ya) {
                 if constexpr (sizeof(AT) == 4) *reinterpret_cast<f32x4*>(ya + orow * lda + 4 * q) = o;
                 else {
-                    u32x2 pk;
-                    pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16); pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
-                    *reinterpret_cast<u32x2*>(ya + orow * lda + 4 * q) = pk;
+                    *reinterpret_cast<u32x2*>(ya + orow * lda + 4 * q) = pack4<AT>(o);
                 }
             }
         }
@@ -135,6 +134,8 @@ __global__ void codes_gather2_kernel(const long long* __restrict__ ids, const fl
     }
 }
 
+template <typename KT> __device__ __forceinline__ void store_kv_elem(KT* p, float v) { *reinterpret_cast<uint16_t*>(p) = H16<KT>::bits(v); }
+
 // fill the KV cache from the prefill's fused q|k|v projection (AT): src (B * rows, ld) with K at column koff + h*64 + d, V at
 // voff + ...; grid.y = batch row b: its `rows` source rows start at b * rows, its planes at b * kv_row_stride elements
 template <typename AT, typename KT>
@@ -148,7 +149,7 @@ __global__ void kv_fill2_kernel(const AT* __restrict__ src, int ld, int koff, in
     const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
     const AT* sp = src + ((size_t)b * rows + r) * ld;
     if constexpr (sizeof(AT) == sizeof(KT)) { kc[dst] = sp[koff + h * 64 + d]; vc[dst] = sp[voff + h * 64 + d]; }     // same type: plain copy
-    else { kc[dst] = f2bf((float)sp[koff + h * 64 + d]); vc[dst] = f2bf((float)sp[voff + h * 64 + d]); }
+    else { store_kv_elem<KT>(kc + dst, (float)sp[koff + h * 64 + d]); store_kv_elem<KT>(vc + dst, (float)sp[voff + h * 64 + d]); }
 }
 
 }  // namespace ma

@@ -69,6 +69,13 @@ struct ChainTimeout : MaError {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// The engine's 16-bit format (ma_config.dtype: MA_DTYPE_BF16 | MA_DTYPE_F16) as a compile-time type of the kernels (common.hpp H16):
+// H16_CALL evaluates an expression, H16_DO runs statements, with HT = f16_t or bf16_t.
+#define H16_CALL(hdt, HT, ...) ((hdt) == MA_DTYPE_F16 ? [&] { using HT = f16_t; return __VA_ARGS__; }() : [&] { using HT = bf16_t; return __VA_ARGS__; }())
+#define H16_DO(hdt, HT, ...) do { if ((hdt) == MA_DTYPE_F16) { using HT = f16_t; __VA_ARGS__; } else { using HT = bf16_t; __VA_ARGS__; } } while (0)
+// 16-bit format of the kernel-level entry points that carry no dtype argument (ma_op_set_half_dtype)
+thread_local int g_op_hdt = MA_DTYPE_BF16;
+
 // roctx ranges around the phases of the hot path (tracing): resolved lazily from libroctx64.so, active only when
 // MA_ROCTX=1 is set in the environment (rocprofv3 --marker-trace then shows encode / prefill / decode / detokenize as ranges)
 struct RoctxRange {
@@ -111,7 +118,8 @@ struct ma_engine {
     void* stage = nullptr; size_t stage_bytes = 0;      // upload staging of ma_engine_load_weights (freed by finalize)
 
     int T = 0, V = 0, maxnew = 0, maxseq = 0, nf = 0, S = 0;
-    bool bf16 = true;
+    bool bf16 = true;                // a 16-bit policy (bf16 OR fp16; the name is historical): 16-bit weights + KV, GEMM / attention inputs rounded
+    int hdt = MA_DTYPE_BF16;         // ... and which one: MA_DTYPE_BF16 | MA_DTYPE_F16 (the type tag of the 16-bit kernels, H16_CALL)
     size_t kv_elem = 2;
     char* kv = nullptr;              // [max_batch][layers][2][heads][maxseq][64] of KT
     size_t kv_plane = 0;             // bytes of one K (or V) plane of one layer
@@ -249,7 +257,7 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
         t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
-        r = launch_gemm_tile(t, s);
+        r = H16_CALL(e->hdt, HT, launch_gemm_tile<HT>(t, s));
     } else {
         GemmArgs g{};
         g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
@@ -270,7 +278,7 @@ GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = 
 void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y32, int ld32, void* ya, int lda, int rows,
             int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}) {
     const float* g = e->PF(prefix + "weight"); const float* b = e->PF(prefix + "bias");
-    if (e->dense16) hipLaunchKernelGGL((ln_rows2_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<bf16_t*>(ya), lda, yout, rows, D);
+    if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((ln_rows2_kernel<HT>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<HT*>(ya), lda, yout, rows, D));
     else hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D);
     HIP_CHECK(hipGetLastError());
 }
@@ -279,21 +287,21 @@ void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, c
                int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0) {
     AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->dense16 ? 3 : 0};
     a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
-    if (e->dense16 && e->opt_attn_impl == 2) {
+    if (e->dense16 && (e->opt_attn_impl == 2 || e->hdt == MA_DTYPE_F16)) {     // (the first-generation kernel, attn_impl 1, is bf16 only)
         if (attn2_vt_elems(Sk, H, batch) > e->vt_elems) throw MaError(MA_ERR_INVALID, "internal: V^T workspace too small");
-        HIP_CHECK(launch_attention2(a, e->a_vt, s));
+        HIP_CHECK(H16_CALL(e->hdt, HT, launch_attention2<HT>(a, e->a_vt, s)));
     } else HIP_CHECK(launch_attention(a, s));
 }
 // fp32 stream rows (row map in, optional row mask) -> activation tensor
 void cvt_rows(ma_engine* e, hipStream_t s, const float* src, int lds, RowMap in, const unsigned char* mask, void* dst, int ldd, int rows, int cols) {
-    if (e->dense16) hipLaunchKernelGGL((cvt_rows_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<bf16_t*>(dst), ldd, rows, cols);
+    if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((cvt_rows_kernel<HT>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<HT*>(dst), ldd, rows, cols));
     else hipLaunchKernelGGL((cvt_rows_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, src, lds, in, mask, reinterpret_cast<float*>(dst), ldd, rows, cols);
     HIP_CHECK(hipGetLastError());
 }
 void add_rows(ma_engine* e, hipStream_t s, const float* in, int ld_in, const unsigned char* mask, const float* t0, const float* tab, int ld_tab, int row0,
               float* out32, int ld_out, void* outa, int ld_outa, int rows, int cols, int tab_mod = 0) {
-    if (e->dense16) hipLaunchKernelGGL((add_rows2_kernel<bf16_t>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
-                                    reinterpret_cast<bf16_t*>(outa), ld_outa, rows, cols, tab_mod);
+    if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((add_rows2_kernel<HT>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
+                                    reinterpret_cast<HT*>(outa), ld_outa, rows, cols, tab_mod));
     else hipLaunchKernelGGL((add_rows2_kernel<float>), dim3(ceil_div(rows * cols, 256)), dim3(256), 0, s, in, ld_in, mask, t0, tab, ld_tab, row0, out32, ld_out,
                             reinterpret_cast<float*>(outa), ld_outa, rows, cols, tab_mod);
     HIP_CHECK(hipGetLastError());
@@ -322,10 +330,10 @@ void encode_chunk(ma_engine* e, hipStream_t s, const void* pc, int pc_dtype, int
     {
         const int total = rowsN * 64;
         if (pc_dtype == MA_DTYPE_F16) {
-            if (e->dense16) hipLaunchKernelGGL((fourier2_kernel<_Float16, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((fourier2_kernel<_Float16, HT>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<HT*>(e->a_feat), 64));
             else hipLaunchKernelGGL((fourier2_kernel<_Float16, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const _Float16*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
         } else {
-            if (e->dense16) hipLaunchKernelGGL((fourier2_kernel<float, bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<bf16_t*>(e->a_feat), 64);
+            if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((fourier2_kernel<float, HT>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<HT*>(e->a_feat), 64));
             else hipLaunchKernelGGL((fourier2_kernel<float, float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, reinterpret_cast<const float*>(pc), rowsN, c.num_freqs, reinterpret_cast<float*>(e->a_feat), 64);
         }
         HIP_CHECK(hipGetLastError());
@@ -380,7 +388,7 @@ void gemv_launch(const GemvArgs& a, hipStream_t s) {
     hipError_t r = launch_gemv<WT>(a, s);
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
 }
-int gemv_blocks(ma_engine* e, int N, int K) { return e->bf16 ? gemv_num_blocks<bf16_t>(N, K) : gemv_num_blocks<float>(N, K); }
+int gemv_blocks(ma_engine* e, int N, int K) { return e->bf16 ? gemv_num_blocks<bf16_t>(N, K) : gemv_num_blocks<float>(N, K); }     // (the two 16-bit formats share their shapes)
 
 struct StepTimer {                    // launch filter (ma_profile_decode) / in-kernel timestamps (ma_trace_decode)
     int only_cls = -1;                // >= 0: enqueue only the launches of this class (0 gemv, 1 attention, 3 pick)
@@ -410,7 +418,7 @@ GemvArgs gemv_base(ma_engine* e, Rows rw) {
     return a;
 }
 void gemv(ma_engine* e, const GemvArgs& a, hipStream_t s, int B) {
-    hipError_t r = e->bf16 ? launch_gemv<bf16_t>(a, s, B) : launch_gemv<float>(a, s, B);
+    hipError_t r = e->bf16 ? H16_CALL(e->hdt, HT, launch_gemv<HT>(a, s, B)) : launch_gemv<float>(a, s, B);
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemv launch failed: ") + hipGetErrorString(r));
 }
 
@@ -427,17 +435,17 @@ void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, ProIn in, cons
     a.ln_g = g; a.ln_b = b; a.ln_eps = 1e-5f;
     a.attn_ws = e->d_part + (size_t)rw.r0 * attn_workspace_floats(c.heads); a.attn_ws_stride = attn_workspace_floats(c.heads); a.attn_heads = c.heads;
     a.xn_out = xn_out; a.xn_stride = c.hidden; a.xb = e->d_xb + (size_t)rw.r0 * c.hidden; a.xb_stride = c.hidden; a.K = c.hidden;
-    hipError_t r = launch_rows_prologue(a, pro, rw.B, s);
+    hipError_t r = H16_CALL(e->hdt, HT, launch_rows_prologue<HT>(a, pro, rw.B, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_prologue launch failed: ") + hipGetErrorString(r));
 }
 void gemm_dec_ln(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
     if (!tm.on(0)) return;
-    hipError_t r = launch_gemm_dec_ln(a, s);
+    hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec_ln<HT>(a, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec_ln launch failed: ") + hipGetErrorString(r));
 }
 void gemm_dec(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
     if (!tm.on(0)) return;
-    hipError_t r = launch_gemm_dec(a, s);
+    hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec<HT>(a, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec launch failed: ") + hipGetErrorString(r));
 }
 
@@ -500,13 +508,13 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             if (tm.on(1)) {
                 // 8..11 rows: two blocks per (row, head) with an in-launch hand-over, so that every CU streams (attn_decode.hpp)
                 const bool pair = pair_ok && B < 12;
-                hipError_t r = launch_attn_decode_final<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems,
-                                                                pair ? 8 : e->opt_attn_final_waves, pair ? e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES : nullptr, e->d_chain_err, l);
+                hipError_t r = H16_CALL(e->hdt, HT, launch_attn_decode_final<HT>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, xb, H, s, B, H, kv_row_elems,
+                                                                pair ? 8 : e->opt_attn_final_waves, pair ? e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES : nullptr, e->d_chain_err, l));
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode_final launch failed: ") + hipGetErrorString(r));
             }
         } else {
             if (tm.on(1)) {
-                hipError_t r = launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems, e->opt_attn_rowwave != 0);
+                hipError_t r = H16_CALL(e->hdt, HT, launch_attn_decode<HT>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, nullptr, B, H, kv_row_elems, e->opt_attn_rowwave != 0));
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
             }
             rows_prologue(e, s, PRO_ATTN, rw, ProIn{}, nullptr, nullptr, nullptr, tm);
@@ -603,7 +611,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         QkvAttnArgs a = make_qkv_attn_args(e, l, x_in, ln_g, ln_b, len_override, rw);
         a.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
         if (tm.on(1)) {
-            hipError_t r = launch_qkv_attn(a, c.heads, B, s);
+            hipError_t r = H16_CALL(e->hdt, HT, launch_qkv_attn<HT>(a, c.heads, B, s));
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("qkv_attn launch failed: ") + hipGetErrorString(r));
         }
     } else {
@@ -617,7 +625,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
     }
     if (tm.on(1)) {
         unsigned long long* tr = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
-        hipError_t r = e->bf16 ? launch_attn_decode<bf16_t>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems)
+        hipError_t r = e->bf16 ? H16_CALL(e->hdt, HT, launch_attn_decode<HT>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 1, part, s, tr, B, H, kv_row_elems))
                                : launch_attn_decode<float>(q, e->kplane(rw.r0, l), e->vplane(rw.r0, l), c.heads, e->maxseq, e->d_st + r0, len_override, 0, part, s, tr, B, H, kv_row_elems);
         if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("attn_decode launch failed: ") + hipGetErrorString(r));
     }
@@ -631,7 +639,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         OprojFc1Args a = make_oproj_fc1_args(e, l, resid, rw, with_fc2);
         a.trace = tm.trace_slot(3, H / 4);
         if (tm.on(0)) {
-            hipError_t r = launch_oproj_fc1(a, H, c.ffn, B, s);
+            hipError_t r = H16_CALL(e->hdt, HT, launch_oproj_fc1<HT>(a, H, c.ffn, B, s));
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("oproj_fc1 launch failed: ") + hipGetErrorString(r));
         }
     } else {
@@ -965,7 +973,7 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
         gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE);
         const int n = T * c.heads * 64;
         if (e->bf16) hipLaunchKernelGGL((kv_fill2_kernel<bf16_t, bf16_t>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, T, c.heads,
-                                        e->maxseq, reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);
+                                        e->maxseq, reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);      // a copy of 16-bit words: either format
         else hipLaunchKernelGGL((kv_fill2_kernel<float, float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const float*>(qkv), 3 * H, H, 2 * H, T, c.heads, e->maxseq,
                                 reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
         HIP_CHECK(hipGetLastError());
@@ -1126,8 +1134,8 @@ void detok_chunk(ma_engine* e, hipStream_t s, const long long* ids, const float*
     // faces (meshanything.py:53-60): codes -> project_down -> zero masked -> + pos -> LN
     {
         const int total = rowsF * 3 * D;
-        if (e->dense16) hipLaunchKernelGGL((codes_gather2_kernel<bf16_t>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
-                                        codes ? nullptr : reinterpret_cast<bf16_t*>(e->a_fein), e->w_mask);
+        if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((codes_gather2_kernel<HT>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
+                                        codes ? nullptr : reinterpret_cast<HT*>(e->a_fein), e->w_mask));
         else hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
                                 codes ? nullptr : reinterpret_cast<float*>(e->a_fein), e->w_mask);
         HIP_CHECK(hipGetLastError());
@@ -1168,7 +1176,7 @@ void validate_config(const ma_config& c) {
     if (c.struct_size != (int32_t)sizeof(ma_config)) bad("struct_size mismatch (header/library version skew)");
     if (c.enc_width != c.enc_heads * 64 || c.hidden != c.heads * 64 || c.tok_width != c.tok_heads * 64) bad("head_dim must be 64 (width = heads*64)");
     if (c.codebook_dim != c.hidden) bad("codebook_dim must equal hidden (word_embed_proj_dim is forced to hidden_size, meshanything.py:112-113)");
-    if (c.dtype != MA_DTYPE_F32 && c.dtype != MA_DTYPE_BF16) bad("dtype must be MA_DTYPE_F32 or MA_DTYPE_BF16");
+    if (c.dtype != MA_DTYPE_F32 && c.dtype != MA_DTYPE_BF16 && c.dtype != MA_DTYPE_F16) bad("dtype must be MA_DTYPE_F32, MA_DTYPE_BF16 or MA_DTYPE_F16");
     const int dims[] = {c.enc_width, c.hidden, c.ffn, c.tok_width, c.tok_ffn, c.embed_dim, c.codebook_dim};
     for (int d : dims) if (d <= 0 || d % 32) bad("GEMM dimensions must be positive multiples of 32");
     if (3 * (2 * c.num_freqs + 1) + 3 > 64 || c.num_freqs < 1 || c.num_freqs > 20) bad("num_freqs out of range");
@@ -1186,7 +1194,7 @@ void build_engine(ma_engine* e) {
     pack_state_init(e->L, e->ps);
     e->T = c.num_latents + 1; e->V = c.codebook_size + 3; e->maxnew = c.n_max_faces * 9 + 2; e->maxseq = e->T + e->maxnew;
     e->nf = c.n_max_faces; e->S = e->T + e->nf;
-    e->bf16 = c.dtype == MA_DTYPE_BF16; e->kv_elem = e->bf16 ? 2 : 4;
+    e->bf16 = c.dtype != MA_DTYPE_F32; e->hdt = c.dtype == MA_DTYPE_F16 ? MA_DTYPE_F16 : MA_DTYPE_BF16; e->kv_elem = e->bf16 ? 2 : 4;
     HIP_CHECK(hipMalloc(&e->arena, e->L.bytes));
     HIP_CHECK(hipMemset(e->arena, 0, e->L.bytes));
     const size_t MB = c.max_batch;
@@ -1419,7 +1427,12 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
-        else if (n == "gemm_variant") gemm_tile_variant() = (int)value;
+        else if (n == "gemm_variant") {
+#ifndef MA_EXPERIMENTAL
+            if (value != 6) throw MaError(MA_ERR_STATE, "gemm_variant: the A/B tile variants need a library built with MA_EXPERIMENTAL=1");
+#endif
+            gemm_tile_variant() = (int)value;
+        }
         else if (n == "gemv_small_rows") {
             if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "gemv_small_rows must be 0, 1, 2 or 4");
             gemv_small_rows() = (int)value; e->embtab_ready = false; drop_graphs(e);
@@ -1523,7 +1536,7 @@ static bool load_tensor_on_device(ma_engine* e, const ma_tensor_desc& t) {
     const int esz = en.dtype == MA_DTYPE_F32 ? 4 : 2;
     void* dst = e->arena + en.offset + s->dst_elem * esz;
     const int blocks = (int)std::min<size_t>((elems + 255) / 256, 65535u * 16u);
-    hipLaunchKernelGGL(cvt_weight_kernel, dim3(blocks), dim3(256), 0, nullptr, e->stage, t.dtype, s->src_cols, dst, esz, en.cols, s->take_rows, s->take_cols);
+    hipLaunchKernelGGL(cvt_weight_kernel, dim3(blocks), dim3(256), 0, nullptr, e->stage, t.dtype, s->src_cols, dst, en.dtype, en.cols, s->take_rows, s->take_cols);
     HIP_CHECK(hipGetLastError());
     e->ps.filled[s->entry] += elems;
     return true;
@@ -1783,7 +1796,9 @@ int ma_op_gemv(int wdtype, const void* W, const float* bias, const float* x, con
         GemvArgs a{};
         a.W = W; a.bias = bias; a.x = x; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.xn_out = xn_out; a.res = res; a.y = y; a.N = N; a.K = K;
         a.act = act; a.round_x = wdtype == MA_DTYPE_BF16; a.epi = EPI_PLAIN;
+        a.round_x = wdtype != MA_DTYPE_F32;
         if (wdtype == MA_DTYPE_BF16) gemv_launch<bf16_t>(a, reinterpret_cast<hipStream_t>(stream));
+        else if (wdtype == MA_DTYPE_F16) gemv_launch<f16_t>(a, reinterpret_cast<hipStream_t>(stream));
         else if (wdtype == MA_DTYPE_F32) gemv_launch<float>(a, reinterpret_cast<hipStream_t>(stream));
         else throw MaError(MA_ERR_INVALID, "ma_op_gemv: wdtype");
     });
@@ -1803,7 +1818,7 @@ int ma_op_gemm(int wdtype, int impl, const float* A, int lda, const void* W, con
             hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(ceil_div(M * K, 256)), dim3(256), 0, s, A, lda, Ab, K, M, K);
             GemmTArgs t{Ab, K, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, nullptr, 0, M, N, K, act};
             t.xcd_swizzle = 1;
-            r = launch_gemm_tile(t, s);
+            r = launch_gemm_tile<bf16_t>(t, s);
             (void)hipStreamSynchronize(s);
             (void)hipFree(Ab);
         } else if (wdtype == MA_DTYPE_BF16) r = launch_gemm<bf16_t>(g, 1, s);                 // the scalar cross-check kernel
@@ -1820,7 +1835,7 @@ int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
         if (!A || !W || (!C && !Cb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_bf16: null pointer");
         GemmTArgs t{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, reinterpret_cast<bf16_t*>(Cb), ldcb, M, N, K, act};
         t.xcd_swizzle = 1;
-        hipError_t r = launch_gemm_tile(t, reinterpret_cast<hipStream_t>(stream));
+        hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_tile<HT>(t, reinterpret_cast<hipStream_t>(stream)));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_bf16: ") + hipGetErrorString(r));
     });
 }
@@ -1843,7 +1858,7 @@ int ma_op_attention(const float* Q, int q_rs, int q_hs, const float* K, int k_rs
         if (round_bf16 == 4) {                               // bf16 tensors, the engine's default kernel (attn2.hpp): V^T packing + swapped-operand attention
             bf16_t* vt = nullptr;
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&vt), attn2_vt_elems(Sk, H, 1) * sizeof(bf16_t)));
-            hipError_t r = launch_attention2(a, vt, s);
+            hipError_t r = H16_CALL(g_op_hdt, HT, launch_attention2<HT>(a, vt, s));
             (void)hipStreamSynchronize(s);
             (void)hipFree(vt);
             if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_attention: ") + hipGetErrorString(r));
@@ -1861,6 +1876,7 @@ int ma_op_decode_attention(int kvdtype, const float* q, const void* kcache, cons
         float* ws = reinterpret_cast<float*>(workspace);
         hipError_t r;
         if (kvdtype == MA_DTYPE_BF16) r = launch_attn_decode<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, ws, s);
+        else if (kvdtype == MA_DTYPE_F16) r = launch_attn_decode<f16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, ws, s);
         else if (kvdtype == MA_DTYPE_F32) r = launch_attn_decode<float>(q, kcache, vcache, H, max_seq, nullptr, len, 0, ws, s);
         else throw MaError(MA_ERR_INVALID, "ma_op_decode_attention: kvdtype");
         HIP_CHECK(r);
@@ -1883,7 +1899,7 @@ int ma_op_decode_attention_rows(const float* q, const void* kcache, const void* 
             HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g), (size_t)B * H * ATTN_PAIR_GRANULES * sizeof(unsigned long long) + 64));
             er = reinterpret_cast<unsigned*>(g + (size_t)B * H * ATTN_PAIR_GRANULES);
             (void)hipMemsetAsync(g, 0, (size_t)B * H * ATTN_PAIR_GRANULES * sizeof(unsigned long long) + 64, s);
-            hipError_t r = launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, 8, g, er, 3);
+            hipError_t r = H16_CALL(g_op_hdt, HT, launch_attn_decode_final<HT>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, 8, g, er, 3));
             unsigned herr = 0;
             (void)hipMemcpyAsync(&herr, er, sizeof(unsigned), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
@@ -1891,7 +1907,7 @@ int ma_op_decode_attention_rows(const float* q, const void* kcache, const void* 
             HIP_CHECK(r);
             if (herr) throw MaError(MA_ERR_HIP, "ma_op_decode_attention_rows: the hand-over between the two blocks of a pair timed out");
         } else if (halves == 1 || halves == 0) {
-            HIP_CHECK(launch_attn_decode_final<bf16_t>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, waves));
+            HIP_CHECK(H16_CALL(g_op_hdt, HT, launch_attn_decode_final<HT>(q, kcache, vcache, H, max_seq, nullptr, len, 1, reinterpret_cast<bf16_t*>(out), H * 64, s, B, H * 64, kv_row_stride, waves)));
         } else throw MaError(MA_ERR_INVALID, "ma_op_decode_attention_rows: halves must be 1 or 2");
     });
 }
@@ -1905,7 +1921,7 @@ int ma_op_gemm_dec(const void* W, const float* bias, const void* xb, const float
         a.W = reinterpret_cast<const bf16_t*>(W); a.bias = bias; a.xb = reinterpret_cast<const bf16_t*>(xb); a.xb_stride = K;
         a.res = res; a.res_stride = N; a.y = y; a.y_stride = N; a.yb = reinterpret_cast<bf16_t*>(yb); a.yb_stride = N;
         a.N = N; a.K = K; a.B = B; a.act = act; a.epi = EPI_PLAIN; a.ksplit = ksplit;
-        hipError_t r = launch_gemm_dec(a, reinterpret_cast<hipStream_t>(stream));
+        hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_dec<HT>(a, reinterpret_cast<hipStream_t>(stream)));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_dec: ") + hipGetErrorString(r));
     });
 }
@@ -1919,7 +1935,7 @@ int ma_op_gemm_dec_ln(const void* W, const float* bias, const float* pin, int pa
         a.N = N; a.K = 1024; a.B = B; a.act = act; a.epi = EPI_PLAIN; a.ksplit = 1;
         a.pin = pin; a.pin_stride = 1024; a.pin_parts = parts; a.pbias = pbias; a.pres = pres; a.pres_stride = 1024;
         a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.xn_out = xn_out; a.xn_stride = 1024;
-        hipError_t r = launch_gemm_dec_ln(a, reinterpret_cast<hipStream_t>(stream));
+        hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_dec_ln<HT>(a, reinterpret_cast<hipStream_t>(stream)));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_dec_ln: ") + hipGetErrorString(r));
     });
 }
@@ -1939,7 +1955,7 @@ int ma_op_gemm_dec_qkv(const void* W, const float* bias, const void* xb, float* 
             a.W = reinterpret_cast<const bf16_t*>(W); a.bias = bias; a.xb = reinterpret_cast<const bf16_t*>(xb); a.xb_stride = H;
             a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1; a.epi = EPI_QKV;
             a.kcache = kcache; a.vcache = vcache; a.kv_row_stride = kv_row_stride; a.H = H; a.max_seq = max_seq; a.st = st;
-            hipError_t r = launch_gemm_dec(a, s);
+            hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_dec<HT>(a, s));
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("ma_op_gemm_dec_qkv: ") + hipGetErrorString(r));
             HIP_CHECK(hipStreamSynchronize(s));
         } catch (...) { (void)hipFree(st); throw; }
@@ -1956,7 +1972,7 @@ int ma_op_rows_prologue(int pro, const float* x, int nparts, int B, const float*
         a.x = x; a.x_stride = K; a.nparts = nparts < 1 ? 1 : nparts; a.B = B; a.bias = bias; a.res = res; a.res_stride = K;
         a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps; a.attn_ws = attn_ws; a.attn_ws_stride = attn_workspace_floats(attn_heads); a.attn_heads = attn_heads;
         a.xn_out = xn_out; a.xn_stride = K; a.xb = reinterpret_cast<bf16_t*>(xb_out); a.xb_stride = K; a.K = K;
-        hipError_t r = launch_rows_prologue(a, pro, B, reinterpret_cast<hipStream_t>(stream));
+        hipError_t r = H16_CALL(g_op_hdt, HT, launch_rows_prologue<HT>(a, pro, B, reinterpret_cast<hipStream_t>(stream)));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_rows_prologue: ") + hipGetErrorString(r));
     });
 }
@@ -1970,6 +1986,12 @@ int ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, const in
                            reinterpret_cast<const int*>(release), (unsigned*)nullptr);
         HIP_CHECK(hipGetLastError());
     });
+}
+
+int ma_op_set_half_dtype(int dtype) {
+    if (dtype != MA_DTYPE_BF16 && dtype != MA_DTYPE_F16) return MA_ERR_INVALID;
+    g_op_hdt = dtype;
+    return MA_OK;
 }
 
 int ma_op_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {

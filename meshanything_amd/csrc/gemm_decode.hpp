@@ -44,7 +44,8 @@ struct GemmDecArgs {
     float* xn_out; int xn_stride;        // LN output fp32 (a later residual), written by block (0, 0); may be null
 };
 
-template <int MT, int CH>
+// HT (all kernels of this file): the 16-bit format of weights, activations and cache (bf16_t | f16_t, common.hpp H16)
+template <int MT, int CH, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
         for (int s = 0; s < CH; ++s)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv[s][t]), acc[t], 0, 0, 0);
+                acc[t] = H16<HT>::mfma16(wv[s], xv[s][t], acc[t]);
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&red[w][t][lane][0]) = acc[t];
@@ -113,11 +114,11 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
             else {
                 const int head = c >> 6, d = c & 63;
                 const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
-                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = f2bf(x);
+                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = H16<HT>::bits(x);
             }
         } else {
             if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
-            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = f2bf(x);
+            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = H16<HT>::bits(x);
         }
     }
 }
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
 // shifted statistics (common.hpp), wave-level reduction -- and parks them in LDS as bf16 (row stride padded by 32 bytes: the 16 rows
 // of an MFMA B fragment land in different banks).  The weight rows of the block (its whole K range: 8 loads per lane) are requested
 // before the prologue.  Same MFMA mapping and epilogues as gemm_dec_kernel.  K = 1024 (the hidden size).
+template <typename HT = bf16_t>
 __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     constexpr int K = 1024, CH = 8, XS = K + 16;             // XS: LDS row stride in bf16 elements (32 bytes of padding: conflict-free fragments)
     __shared__ __attribute__((aligned(16))) float red[4][64][4];
@@ -180,10 +182,7 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + idx), bb = *reinterpret_cast<const f32x4*>(a.ln_b + idx);
             ln_apply(xv[j], md, rstd, g, bb);
             if (writer) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)r * a.xn_stride + idx) = xv[j];
-            u32x2 pk;
-            pk.x = (uint32_t)f2bf(xv[j].x) | ((uint32_t)f2bf(xv[j].y) << 16);
-            pk.y = (uint32_t)f2bf(xv[j].z) | ((uint32_t)f2bf(xv[j].w) << 16);
-            *reinterpret_cast<u32x2*>(&xl[r * XS + idx]) = pk;
+            *reinterpret_cast<u32x2*>(&xl[r * XS + idx]) = pack4<HT>(xv[j]);
         }
     };
     for (int r = w; r < a.B; r += 8) {
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
         const u32x4 xv = *reinterpret_cast<const u32x4*>(xr + s * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s]), __builtin_bit_cast(bf16x8_t, xv), acc, 0, 0, 0);
+        acc = H16<HT>::mfma16(wv[s], xv, acc);
     }
     *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
     __syncthreads();
@@ -233,19 +232,20 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
             else {
                 const int head = c >> 6, d = c & 63;
                 const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
-                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = f2bf(x);
+                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = H16<HT>::bits(x);
             }
         } else {
             if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
-            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = f2bf(x);
+            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = H16<HT>::bits(x);
         }
     }
 }
 
+template <typename HT>
 inline hipError_t launch_gemm_dec_ln(const GemmDecArgs& a, hipStream_t s) {
     if (a.K != 1024 || a.B < 1 || a.B > 16 || a.ksplit != 1 || !a.pin || a.pin_parts < 1 || !a.ln_g || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) ||
         (a.xn_out && a.xn_stride % 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_dec_ln_kernel, dim3((a.N + 15) / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_dec_ln_kernel<HT>), dim3((a.N + 15) / 16), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -257,15 +257,16 @@ inline int gemm_dec_ksplit(int N, int K) {
     return 1;
 }
 
+template <typename HT>
 inline hipError_t launch_gemm_dec(const GemmDecArgs& a, hipStream_t s) {
     if (a.ksplit < 1 || a.K % (4 * a.ksplit * 32) != 0 || a.B < 1 || a.B > 64) return hipErrorInvalidValue;
     if (a.ksplit > 1 && (!a.y || a.epi != EPI_PLAIN)) return hipErrorInvalidValue;
     const dim3 grid((a.N + 15) / 16, a.ksplit), block(256);
     const int mt = (a.B + 15) / 16;
-    if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1, 8>), grid, block, 0, s, a);
-    else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2, 8>), grid, block, 0, s, a);
-    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3, 4>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_dec_kernel<4, 4>), grid, block, 0, s, a);
+    if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1, 8, HT>), grid, block, 0, s, a);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2, 8, HT>), grid, block, 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3, 4, HT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_dec_kernel<4, 4, HT>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
@@ -284,7 +285,7 @@ struct RowsProArgs {
 
 // thread t owns the float4 chunks t, t+256, ... of its row: the same partition, arithmetic and summation order as the
 // block-level prologue of gemv_kernel, so a batched row sees the same activation bits as a batch-1 run
-template <int PRO>
+template <int PRO, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x, K = a.K;
@@ -352,19 +353,17 @@ __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
         const int idx = tid + 256 * j;
         if (idx < nq) {
             if (a.xn_out) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)b * a.xn_stride + idx * 4) = xv[j];
-            u32x2 pk;
-            pk.x = (uint32_t)f2bf(xv[j].x) | ((uint32_t)f2bf(xv[j].y) << 16);
-            pk.y = (uint32_t)f2bf(xv[j].z) | ((uint32_t)f2bf(xv[j].w) << 16);
-            *reinterpret_cast<u32x2*>(a.xb + (size_t)b * a.xb_stride + idx * 4) = pk;
+            *reinterpret_cast<u32x2*>(a.xb + (size_t)b * a.xb_stride + idx * 4) = pack4<HT>(xv[j]);
         }
     }
 }
 
+template <typename HT>
 inline hipError_t launch_rows_prologue(const RowsProArgs& a, int pro, int B, hipStream_t s) {
     if (a.K % 4 != 0 || a.K > 4096 || (pro == PRO_ATTN && (a.K > 1024 || a.K != a.attn_heads * 64))) return hipErrorInvalidValue;
-    if (pro == PRO_LN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_LN>), dim3(B), dim3(256), 0, s, a);
-    else if (pro == PRO_ATTN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_ATTN>), dim3(B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rows_prologue_kernel<PRO_PLAIN>), dim3(B), dim3(256), 0, s, a);
+    if (pro == PRO_LN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_LN, HT>), dim3(B), dim3(256), 0, s, a);
+    else if (pro == PRO_ATTN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_ATTN, HT>), dim3(B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rows_prologue_kernel<PRO_PLAIN, HT>), dim3(B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

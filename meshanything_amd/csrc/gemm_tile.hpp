@@ -57,7 +57,8 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_
 // (its ds_reads retired by the lgkmcnt(0) in front of this barrier).
 // WM x WN waves (default 2 x 2): each wave a (BM / WM) x (BN / WN) sub-tile.  The 4 x 2 form carries a 256 x 128 block tile on 8 waves: a
 // third less LDS fill per FLOP than 128 x 128 (the loop is bound by the LDS-DMA issue and fill rate, not by the matrix cores).
-template <int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
+// HT: the 16-bit format of both operands and of the 16-bit output (bf16_t | f16_t, common.hpp H16)
+template <typename HT, int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
     constexpr int NW = WM * WN;
     constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
@@ -129,22 +130,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
         const char* sw = sa + A_BYTES;
 #pragma unroll
         for (int s = 0; s < BK / 32; ++s) {
-            bf16x8_t wf[TN], xf[TM];
+            u32x4 wf[TN], xf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int r = wn * (BN / WN) + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const bf16x8_t*>(sw + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
+                wf[i] = *reinterpret_cast<const u32x4*>(sw + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int r = wm * (BM / WM) + j * 16 + fr;
-                xf[j] = *reinterpret_cast<const bf16x8_t*>(sa + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
+                xf[j] = *reinterpret_cast<const u32x4*>(sa + r * ROWB + (((s * 4 + kg) ^ swz(r)) * 16));
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = H16<HT>::mfma16(wf[i], xf[j], acc[i][j]);
         }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -172,10 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
                 if (g.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(g.R + mr * g.ldr + n0); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
                 if (g.C) *reinterpret_cast<f32x4*>(g.C + mo * g.ldc + n0) = v;
                 if (g.Cb) {
-                    u32x2 pk;
-                    pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-                    pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-                    *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + n0) = pk;
+                    *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + n0) = pack4<HT>(v);
                 }
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -183,68 +181,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
                     float t = vv[r];
                     if (g.R) t += g.R[mr * g.ldr + n0 + r];
                     if (g.C) g.C[mo * g.ldc + n0 + r] = t;
-                    if (g.Cb) g.Cb[mo * g.ldcb + n0 + r] = f2bf(t);
+                    if (g.Cb) g.Cb[mo * g.ldcb + n0 + r] = H16<HT>::bits(t);
                 }
             }
         }
     }
 }
 
-// variant knob (engine option gemm_variant; A/B in profiles/): 0 = K-tile 64, 2 stages | 1 = K-tile 32, 4 stages | 2 = K-tile 32, 5 stages |
+// variant knob (engine option gemm_variant; only libraries built with MA_EXPERIMENTAL=1 honour values other than the default 6; A/B in
+// profiles/): 0 = K-tile 64, 2 stages | 1 = K-tile 32, 4 stages | 2 = K-tile 32, 5 stages |
 // 3 = K-tile 64, 3 stages (one block per CU) | 4 = K-tile 64, 3 stages, raw barrier | 5 = K-tile 32, 4 stages, raw barrier | 6 = K-tile 64,
 // 2 stages, raw barrier (default) | 7 = K-tile 32, 6 stages, raw barrier | 8 = the 128 x 64 tile for every shape (A/B of the tail rounds)
 inline int& gemm_tile_variant() { static int v = 6; return v; }      // 6: +2 ... +13 % over 0 on the path's shapes (profiles/r03_ab_dense_attention_gemm_variants.txt)
 
-template <int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
+template <typename HT, int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
 inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static bool attr = false;
     if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<HT, BM, BN, BK, NS, RAW, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
+    hipLaunchKernelGGL((gemm_tile_kernel<HT, BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
     return hipGetLastError();
 }
 
 // 16-byte DMA sources and vector epilogue accesses need: lda % 8 == 0, K % 32 == 0, ldc / ldr % 4 == 0, ldcb % 4 == 0
+template <typename HT>
 inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
     const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
     const int v = gemm_tile_variant();
-    if (v == 8 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 2, true>(g, s);      // A/B: the half tile everywhere
-    if (v == 12 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 64, 2, true, 4, 2>(g, s);    // A/B: 256 x 128 tile, 8 waves, 96 KB
-    if (v == 13 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 64, 3, true, 4, 2>(g, s);    // A/B: ... three stages, 144 KB
-    if (v == 14 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<256, 128, 32, 4, true, 4, 2>(g, s);    // A/B: ... K-tile 32, four stages, 96 KB
-    if (v == 9 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 3, true>(g, s);     // A/B: 48 KB of LDS: three blocks per CU
-    if (v == 10 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<128, 64, 64, 3, true>(g, s);     // A/B: half tile, two K-tiles in flight
-    if (v == 11 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<128, 128, 32, 2, true>(g, s);    // A/B: 32 KB of LDS: four-five blocks per CU
+#ifdef MA_EXPERIMENTAL
+    // the A/B variants of rounds 2-3 (profiles/r02_ab_gemm_tile_stages.txt, r03_ab_gemm_tile_occupancy_and_tail.txt): evidence, not product
+    if (v == 8 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<HT, 128, 64, 64, 2, true>(g, s);      // the half tile everywhere
+    if (v == 12 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<HT, 256, 128, 64, 2, true, 4, 2>(g, s);    // 256 x 128 tile, 8 waves, 96 KB
+    if (v == 13 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<HT, 256, 128, 64, 3, true, 4, 2>(g, s);    // ... three stages, 144 KB
+    if (v == 14 && g.K % 64 == 0 && g.M > 128 && g.N > 64) return gt_launch<HT, 256, 128, 32, 4, true, 4, 2>(g, s);    // ... K-tile 32, four stages, 96 KB
+    if (v == 9 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<HT, 128, 128, 32, 3, true>(g, s);     // 48 KB of LDS: three blocks per CU
+    if (v == 10 && g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<HT, 128, 64, 64, 3, true>(g, s);     // half tile, two K-tiles in flight
+    if (v == 11 && g.K % 64 == 0 && g.M > 64 && g.N > 64) return gt_launch<HT, 128, 128, 32, 2, true>(g, s);    // 32 KB of LDS: four-five blocks per CU
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) {
+        if (v == 1) return gt_launch<HT, 128, 128, 32, 4>(g, s);
+        if (v == 2) return gt_launch<HT, 128, 128, 32, 5>(g, s);
+        if (v == 3) return gt_launch<HT, 128, 128, 64, 3>(g, s);
+        if (v == 4) return gt_launch<HT, 128, 128, 64, 3, true>(g, s);
+        if (v == 5) return gt_launch<HT, 128, 128, 32, 4, true>(g, s);
+        if (v == 7) return gt_launch<HT, 128, 128, 32, 6, true>(g, s);
+        if (v == 0) return gt_launch<HT, 128, 128, 64, 2>(g, s);
+    }
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 32 && tiles128 < 160) {
+        if (v == 1 || v == 2) return gt_launch<HT, 128, 64, 32, 5>(g, s);
+        if (v == 3) return gt_launch<HT, 128, 64, 64, 3>(g, s);
+        if (v == 0) return gt_launch<HT, 128, 64, 64, 2>(g, s);
+    }
+#endif
+    (void)v;
     // Problems with many tiles (the detokenizer's M = B x 1057, wide N): the 256 x 128 tile on 8 waves with three LDS stages (144 KB, one block
     // per CU) -- a third less LDS fill per FLOP.  Isolated: 569 vs 504 TFLOP/s (67648 x 3072 x 768), 602 vs 514 (262144 x 1536 x 768), 983 vs
     // 720-868 on 8192^3 (profiles/r03_ab_gemm_tile_occupancy_and_tail.txt); inside the pipeline the detokenizer gains 2.6 %, the encoder's
-    // 262144-row GEMM loses (profiles/r03_ab_dense_gemm_selection_in_pipeline.txt), so it is kept to 2048 .. 16384 tiles of M <= 131072.  The
-    // higher-occupancy K-tile-32 form that wins 10-20 % in isolation on the OPT-prefill shapes measures no gain in the pipeline: not used.
-    if (v == 6 && g.K % 64 == 0 && g.M > 128 && g.M <= 131072 && g.N > 64 && tiles128 >= 2048) return gt_launch<256, 128, 64, 3, true, 4, 2>(g, s);
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) {
-        if (v == 1) return gt_launch<128, 128, 32, 4>(g, s);
-        if (v == 2) return gt_launch<128, 128, 32, 5>(g, s);
-        if (v == 3) return gt_launch<128, 128, 64, 3>(g, s);
-        if (v == 4) return gt_launch<128, 128, 64, 3, true>(g, s);
-        if (v == 5) return gt_launch<128, 128, 32, 4, true>(g, s);
-        if (v == 6) return gt_launch<128, 128, 64, 2, true>(g, s);
-        if (v == 7) return gt_launch<128, 128, 32, 6, true>(g, s);
-        if (v == 0) return gt_launch<128, 128, 64, 2>(g, s);
-        return gt_launch<128, 128, 64, 2, true>(g, s);
-    }
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 32) {      // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
-        if (v == 1 || v == 2) return gt_launch<128, 64, 32, 5>(g, s);
-        if (v == 3) return gt_launch<128, 64, 64, 3>(g, s);
-        if (v == 0) return gt_launch<128, 64, 64, 2>(g, s);
-        return gt_launch<128, 64, 64, 2, true>(g, s);
-    }
-    return gt_launch<64, 64, 32, 2>(g, s);
+    // 262144-row GEMM loses (profiles/r03_ab_dense_gemm_selection_in_pipeline.txt), so it is kept to 2048 .. 16384 tiles of M <= 131072.
+    if (g.K % 64 == 0 && g.M > 128 && g.M <= 131072 && g.N > 64 && tiles128 >= 2048) return gt_launch<HT, 256, 128, 64, 3, true, 4, 2>(g, s);
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) return gt_launch<HT, 128, 128, 64, 2, true>(g, s);
+    // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
+    if (g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<HT, 128, 64, 64, 2, true>(g, s);
+    return gt_launch<HT, 64, 64, 32, 2>(g, s);
 }
 
 // fp32 -> bf16 rows (kernel-level entry point ma_op_gemm with a bf16 weight and an fp32 activation matrix; small utility elsewhere)

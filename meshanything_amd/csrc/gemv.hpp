@@ -58,20 +58,19 @@ struct GemvArgs {
 template <typename WT> struct WTraits;
 template <> struct WTraits<float>  { static constexpr int VEC = 4; };
 template <> struct WTraits<bf16_t> { static constexpr int VEC = 8; };
+template <> struct WTraits<f16_t> { static constexpr int VEC = 8; };
 
 template <typename WT>
 __device__ inline void unpack16(const u32x4& w, float* f) {
     if constexpr (sizeof(WT) == 4) {
         f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
-    } else {
-        f[0] = bf_lo(w.x); f[1] = bf_hi(w.x); f[2] = bf_lo(w.y); f[3] = bf_hi(w.y);
-        f[4] = bf_lo(w.z); f[5] = bf_hi(w.z); f[6] = bf_lo(w.w); f[7] = bf_hi(w.w);
-    }
+    } else unpack8<WT>(w, f);
 }
 
-template <typename KT> __device__ inline void store_kv(KT* p, float v);
-template <> __device__ inline void store_kv<float>(float* p, float v) { *p = v; }
-template <> __device__ inline void store_kv<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <typename KT> __device__ inline void store_kv(KT* p, float v) {
+    if constexpr (sizeof(KT) == 4) *p = v;
+    else *reinterpret_cast<uint16_t*>(p) = H16<KT>::bits(v);
+}
 
 // Work decomposition: one block = 4 waves = RPB = (4/KSPLIT)*RPW output rows; KSPLIT waves share a group of RPW rows,
 // each owning LPL 16-byte pieces per lane and row (K = KC = KSPLIT * LPL * 64 * VEC).  Lane j of the first wave of a
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
             if (idx < KC / 4) {
                 if (a.xn_out && blockIdx.x == 0) *reinterpret_cast<f32x4*>(a.xn_out + idx * 4) = xv[j];
                 f32x4 r = xv[j];
-                if (a.round_x) { r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w); }
+                if (a.round_x) { r.x = H16<WT>::round(r.x); r.y = H16<WT>::round(r.y); r.z = H16<WT>::round(r.z); r.w = H16<WT>::round(r.w); }
                 *reinterpret_cast<f32x4*>(&xl[idx * 4]) = r;
             }
         }
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                     else t = x[k0 + v];
                     if constexpr (PRO == PRO_LN) t = (t - mean) * rstd * a.ln_g[k0 + v] + a.ln_b[k0 + v];
                     if (a.xn_out && blockIdx.x == 0 && w == 0) a.xn_out[k0 + v] = t;
-                    xv[v] = a.round_x ? round_bf16(t) : t;
+                    xv[v] = a.round_x ? H16<WT>::round(t) : t;
                 }
                 u32x4 wq = ld_stream16(W + (size_t)rowc * K + k0);
                 float wf[VEC];

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void layer_fused_kernel(LayerFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float ynext[1024];
     const int c = blockIdx.x, h = blockIdx.y, brow = blockIdx.z;
     QkvOperands op;                                      // layer l + 1's weight rows: requested while relu(fc1) is being gathered
-    oproj_fc1_body<4, true, true>(a.o, h * ATTN_NCHUNK + c, brow, ynext, a.gran3, [&] { qkv_load_operands<PRO_LN>(a.q, c, h, op); asm volatile("" ::: "memory"); });
+    oproj_fc1_body<4, true, true, bf16_t>(a.o, h * ATTN_NCHUNK + c, brow, ynext, a.gran3, [&] { qkv_load_operands<PRO_LN>(a.q, c, h, op); asm volatile("" ::: "memory"); });
     qkv_attn_body<PRO_LN, true>(a.q, c, h, gridDim.y, brow, ynext, op);
 }
 

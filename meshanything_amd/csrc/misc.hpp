@@ -222,7 +222,8 @@ __global__ void fill_tokens_kernel(long long* p, long long v, int n) {
 
 // checkpoint tensor (fp32 | bf16 | fp16 as stored, rows x src_ld) -> its arena slot (fp32 or bf16, leading dimension dst_ld): the device
 // half of ma_engine_load_weights.  Same rounding as the host packer (f2bf: round to nearest even).
-__global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, int src_ld, void* __restrict__ dst, int dst_esz, int dst_ld, int rows, int cols) {
+// dst_dtype: MA_DTYPE_F32 | MA_DTYPE_BF16 | MA_DTYPE_F16 (the arena entry's type)
+__global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, int src_ld, void* __restrict__ dst, int dst_dtype, int dst_ld, int rows, int cols) {
     const size_t total = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / cols, k = i - r * cols, si = r * src_ld + k;
@@ -230,7 +231,8 @@ __global__ void cvt_weight_kernel(const void* __restrict__ src, int src_dtype, i
         if (src_dtype == MA_DTYPE_F32) v = reinterpret_cast<const float*>(src)[si];
         else if (src_dtype == MA_DTYPE_BF16) v = bf2f(reinterpret_cast<const uint16_t*>(src)[si]);
         else v = (float)reinterpret_cast<const _Float16*>(src)[si];
-        if (dst_esz == 4) reinterpret_cast<float*>(dst)[r * dst_ld + k] = v;
+        if (dst_dtype == MA_DTYPE_F32) reinterpret_cast<float*>(dst)[r * dst_ld + k] = v;
+        else if (dst_dtype == MA_DTYPE_F16) reinterpret_cast<uint16_t*>(dst)[r * dst_ld + k] = H16<f16_t>::bits(v);
         else reinterpret_cast<bf16_t*>(dst)[r * dst_ld + k] = f2bf(v);
     }
 }

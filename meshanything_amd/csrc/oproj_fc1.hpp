@@ -47,7 +47,8 @@ constexpr unsigned OF_ERR_GATHER = 32;
 // NEXT: instead of storing y2, all-gather it (1024 granules in `gran3`, a quarter per wave) into `ynext` (LDS, 1024 floats): the next
 // layer's q/k/v + attention continues in the same launch (layer_fused.hpp).  Arguments by value: a by-reference kernel-argument
 // struct can end up in scratch.
-template <int NSW, bool FC2, bool NEXT, typename Hook>
+// HT: the 16-bit format of the weights (bf16_t | f16_t, common.hpp H16)
+template <int NSW, bool FC2, bool NEXT, typename HT, typename Hook>
 __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, const int brow, float* ynext, u64* gran3, Hook&& after_ffn_publish) {
     constexpr int KC = 1024, KF = 4096;
     __shared__ __attribute__((aligned(16))) float ffl[FC2 ? KF : 4];      // relu(fc1), rounded to bf16 (fc2's input)
@@ -91,7 +92,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------
     {
         f32x4 r = attn_partials_merge(pml, po);
-        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        r.x = H16<HT>::round(r.x); r.y = H16<HT>::round(r.y); r.z = H16<HT>::round(r.z); r.w = H16<HT>::round(r.w);
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
     }
     __syncthreads();
@@ -107,7 +108,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
                 xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
             }
-            unpack16<bf16_t>(wo[i], wf);
+            unpack16<HT>(wo[i], wf);
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
         }
@@ -175,7 +176,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         if constexpr (FC2) { if (tid == b) { h1l[0] = xv[0].x; h1l[1] = xv[0].y; h1l[2] = xv[0].z; h1l[3] = xv[0].w; } }   // elements 4b .. 4b + 3
         else if (b == 0) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)brow * a.h1_stride + tid * 4) = xv[0];
         f32x4 r = xv[0];
-        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        r.x = H16<HT>::round(r.x); r.y = H16<HT>::round(r.y); r.z = H16<HT>::round(r.z); r.w = H16<HT>::round(r.w);
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
     }
     __syncthreads();
@@ -192,7 +193,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float wf[8];
-            unpack16<bf16_t>(w1[j][i], wf);
+            unpack16<HT>(w1[j][i], wf);
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc4[j] = fmaf(wf[v], xs[v], acc4[j]);
         }
@@ -214,7 +215,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         u64* g2 = a.gran2 + (size_t)brow * KF;
         {
             const float nb = __shfl_down(outv, 1, 64);
-            if (lane == 0 || lane == 2) ps_publish(g2, 8 * b + 2 * w + (lane >> 1), epoch, (unsigned)f2bf(outv) | ((unsigned)f2bf(nb) << 16));
+            if (lane == 0 || lane == 2) ps_publish(g2, 8 * b + 2 * w + (lane >> 1), epoch, H16<HT>::pack2(outv, nb));
         }
         after_ffn_publish();                             // the caller's next requests ride under this exchange
         {
@@ -233,7 +234,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 for (int k = 0; k < 8; ++k) {
                     if ((pend >> k) & 1u) {
                         const bool ok = (unsigned)(v[k] >> 32) == epoch;
-                        if (ok) { const unsigned pr = (unsigned)v[k]; fr[2 * (k * 64 + lane)] = bf_lo(pr); fr[2 * (k * 64 + lane) + 1] = bf_hi(pr); }
+                        if (ok) { const unsigned pr = (unsigned)v[k]; fr[2 * (k * 64 + lane)] = H16<HT>::lo(pr); fr[2 * (k * 64 + lane) + 1] = H16<HT>::hi(pr); }
                         if (__all(ok)) pend &= ~(1u << k);
                     }
                 }
@@ -261,7 +262,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&ffl[k0 + v]);
                 xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
             }
-            unpack16<bf16_t>(w2[i], wf);
+            unpack16<HT>(w2[i], wf);
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
         }
@@ -307,17 +308,18 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     }
 }
 
-template <int NSW, bool FC2>
+template <int NSW, bool FC2, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void oproj_fc1_kernel(OprojFc1Args a) {
-    oproj_fc1_body<NSW, FC2, false>(a, blockIdx.x, blockIdx.y, nullptr, nullptr, [] {});
+    oproj_fc1_body<NSW, FC2, false, HT>(a, blockIdx.x, blockIdx.y, nullptr, nullptr, [] {});
 }
 
+template <typename HT>
 inline hipError_t launch_oproj_fc1(const OprojFc1Args& a, int hidden, int ffn, int batch, hipStream_t s) {
     if (hidden != 1024 || ffn != 4096 || a.heads * 64 != hidden) return hipErrorInvalidValue;
-    if (a.W2) hipLaunchKernelGGL((oproj_fc1_kernel<4, true>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
-    else if (a.sweep_waves == 2) hipLaunchKernelGGL((oproj_fc1_kernel<2, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
-    else if (a.sweep_waves == 4) hipLaunchKernelGGL((oproj_fc1_kernel<4, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((oproj_fc1_kernel<1, false>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    if (a.W2) hipLaunchKernelGGL((oproj_fc1_kernel<4, true, HT>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else if (a.sweep_waves == 2) hipLaunchKernelGGL((oproj_fc1_kernel<2, false, HT>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else if (a.sweep_waves == 4) hipLaunchKernelGGL((oproj_fc1_kernel<4, false, HT>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((oproj_fc1_kernel<1, false, HT>), dim3(hidden / 4, batch), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

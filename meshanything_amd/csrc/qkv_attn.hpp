@@ -63,15 +63,16 @@ __device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const in
 
 // XLDS: the input vector is already in LDS (`xlds`, 1024 floats; layer_fused.hpp) instead of global memory, and the operands were
 // requested by the caller.
-template <int PRO, bool XLDS>
+// HT: the 16-bit format of the weights and the cache (bf16_t | f16_t, common.hpp H16)
+template <int PRO, bool XLDS, typename HT = bf16_t>
 __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const int h, const int nheads, const int brow, const float* xlds, QkvOperands& op) {
-    typedef AttnGeom<bf16_t> G;
+    typedef AttnGeom<HT> G;
     constexpr int KC = 1024;
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ float red[8];
     __shared__ __attribute__((aligned(16))) float qg[64];            // q_h, already rounded to bf16 (one conversion per lane, by the sweeping wave)
     __shared__ __attribute__((aligned(16))) bf16_t kvg[128];        // newest position's k_h | v_h as bf16 (what the cache holds)
-    __shared__ AttnMergeLds<bf16_t> S;
+    __shared__ AttnMergeLds<HT> S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Hd = a.hidden;
     const u64 t_block = __builtin_amdgcn_s_memrealtime();
@@ -112,7 +113,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     if (a.xn_out && c == 0 && h == 0) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)brow * a.xn_stride + tid * 4) = xv[0];
     {
         f32x4 r = xv[0];
-        r.x = round_bf16(r.x); r.y = round_bf16(r.y); r.z = round_bf16(r.z); r.w = round_bf16(r.w);
+        r.x = H16<HT>::round(r.x); r.y = H16<HT>::round(r.y); r.z = H16<HT>::round(r.z); r.w = H16<HT>::round(r.w);
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
     }
     __syncthreads();
@@ -129,7 +130,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             float wf[8];
-            unpack16<bf16_t>(op.wv[p][i], wf);
+            unpack16<HT>(op.wv[p][i], wf);
 #pragma unroll
             for (int v = 0; v < 8; ++v) acc[p] = fmaf(wf[v], xs[v], acc[p]);
         }
@@ -162,9 +163,9 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
                 ok = ok && (unsigned)(v[p] >> 32) == epoch;
             }
             if (__all(ok)) {
-                qg[lane] = round_bf16(__uint_as_float((unsigned)v[0]));
-                kvg[lane] = f2bf(__uint_as_float((unsigned)v[1]));
-                kvg[64 + lane] = f2bf(__uint_as_float((unsigned)v[2]));
+                qg[lane] = H16<HT>::round(__uint_as_float((unsigned)v[0]));
+                kvg[lane] = H16<HT>::bits(__uint_as_float((unsigned)v[1]));
+                kvg[64 + lane] = H16<HT>::bits(__uint_as_float((unsigned)v[2]));
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -192,16 +193,16 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     }
     const u32x4 ok4 = *reinterpret_cast<const u32x4*>(kvg + dsub * G::EPL), ov4 = *reinterpret_cast<const u32x4*>(kvg + 64 + dsub * G::EPL);
     const int ovr = c == c_last ? pos : -1;
-    AttnSlotState<bf16_t> ss;
+    AttnSlotState<HT> ss;
     ss.m = -1e30f; ss.l = 0.f;
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) ss.o[e] = 0.f;
     for (int r = 0; r < nround; r += 2) {
         if (r + 1 < nround) issue(r + 1, kB, vB);
-        attn_round_reduce<bf16_t, true>(ss, qv, kA, vA, start + (r << 7) + woff + slot, end, ovr, ok4, ov4);
+        attn_round_reduce<HT, true>(ss, qv, kA, vA, start + (r << 7) + woff + slot, end, ovr, ok4, ov4);
         if (r + 1 < nround) {
             if (r + 2 < nround) issue(r + 2, kA, vA);
-            attn_round_reduce<bf16_t, true>(ss, qv, kB, vB, start + ((r + 1) << 7) + woff + slot, end, ovr, ok4, ov4);
+            attn_round_reduce<HT, true>(ss, qv, kB, vB, start + ((r + 1) << 7) + woff + slot, end, ovr, ok4, ov4);
         }
     }
     const int gs = w * G::PPW + slot;
@@ -211,14 +212,14 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     __syncthreads();
     {
         float M, L, O;
-        attn_fold_quarter<bf16_t>(S, w, lane, M, L, O);
+        attn_fold_quarter<HT>(S, w, lane, M, L, O);
         if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
         S.qo[w][lane] = O;
     }
     __syncthreads();
     if (w == 0) {
         float M, L, O;
-        attn_fold_block<bf16_t>(S, lane, M, L, O);
+        attn_fold_block<HT>(S, lane, M, L, O);
         float* ws = a.ws + (size_t)brow * attn_workspace_floats(nheads);
         float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
         float* op = ws + (size_t)nheads * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
@@ -241,19 +242,20 @@ __device__ __forceinline__ void qkv_block_role(const QkvAttnArgs& a, int& c, int
     }
 }
 
-template <int PRO>
+template <int PRO, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
     QkvOperands op;
     int c, h;
     qkv_block_role(a, c, h);
-    qkv_attn_body<PRO, false>(a, c, h, gridDim.y, blockIdx.z, nullptr, op);
+    qkv_attn_body<PRO, false, HT>(a, c, h, gridDim.y, blockIdx.z, nullptr, op);
 }
 
+template <typename HT>
 inline hipError_t launch_qkv_attn(const QkvAttnArgs& a, int heads, int batch, hipStream_t s) {
     if (a.hidden != 1024 || heads * 64 != a.hidden) return hipErrorInvalidValue;
     const dim3 grid(ATTN_NCHUNK, heads, batch);
-    if (a.ln_g) hipLaunchKernelGGL((qkv_attn_kernel<PRO_LN>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((qkv_attn_kernel<PRO_PLAIN>), grid, dim3(256), 0, s, a);
+    if (a.ln_g) hipLaunchKernelGGL((qkv_attn_kernel<PRO_LN, HT>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((qkv_attn_kernel<PRO_PLAIN, HT>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

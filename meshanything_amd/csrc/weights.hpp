@@ -19,7 +19,7 @@ namespace ma {
 struct Entry {
     std::string name;
     int rows, cols;      // cols = padded leading dimension
-    int dtype;           // MA_DTYPE_F32 or MA_DTYPE_BF16
+    int dtype;           // MA_DTYPE_F32, MA_DTYPE_BF16 or MA_DTYPE_F16
     size_t offset, bytes;
     size_t want;         // elements the checkpoint must write into this entry (padding excluded)
 };
@@ -72,7 +72,7 @@ inline void layout_miche_block(Layout& L, const std::string& p, int W, int mdt) 
 
 inline Layout build_layout(const ma_config& c) {
     Layout L;
-    const int mdt = c.dtype == MA_DTYPE_F32 ? MA_DTYPE_F32 : MA_DTYPE_BF16;
+    const int mdt = c.dtype == MA_DTYPE_F32 ? MA_DTYPE_F32 : (c.dtype == MA_DTYPE_F16 ? MA_DTYPE_F16 : MA_DTYPE_BF16);
     // the point encoder's matrices (and the two projections of its latents in front of the decoder and of the detokenizer): fp32 when
     // cfg.enc_exact asks for the exact encoder under a 16-bit policy (engine.hip, DenseScope)
     const int edt = (c.dtype == MA_DTYPE_F32 || c.enc_exact) ? MA_DTYPE_F32 : mdt;
@@ -222,7 +222,7 @@ inline int pack_tensor(const Layout& L, PackState& ps, const ma_tensor_desc& t, 
                 for (int k = 0; k < s->take_cols; ++k) {
                     const float v = src_elem(t.data, t.dtype, r * s->src_cols + k);
                     if (esz == 4) reinterpret_cast<float*>(dst)[k] = v;
-                    else reinterpret_cast<uint16_t*>(dst)[k] = f2bf(v);
+                    else reinterpret_cast<uint16_t*>(dst)[k] = e.dtype == MA_DTYPE_F16 ? float2half_host(v) : f2bf(v);
                 }
             }
         }

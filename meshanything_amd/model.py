@@ -17,7 +17,7 @@ thin call into libmeshanything_amd.so through `Engine` (no arithmetic happens in
 
 `args` needs the attributes the reference reads: `.llm` (config name only; ignored like the reference ignores its
 weights), `.codebook_size`, `.codebook_dim`, `.n_max_triangles` (meshanything.py:19-20,93,96).  Extra, optional:
-`.dtype` ("bf16" | "fp32"), `.batchsize_per_gpu` (engine max_batch), `.device` (GPU index).
+`.dtype` ("bf16" | "fp16" | "fp32"), `.batchsize_per_gpu` (engine max_batch), `.device` (GPU index).
 """
 from __future__ import annotations
 
@@ -26,7 +26,7 @@ from typing import Dict, Mapping, Optional
 
 import torch
 
-from .config import DTYPE_BF16, DTYPE_F32, MAConfig
+from .config import DTYPE_BF16, DTYPE_F16, DTYPE_F32, MAConfig
 from .engine import Engine
 
 BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID = 0, 1, 2        # meshanything.py:102-104
@@ -35,7 +35,7 @@ BOS_TOKEN_ID, EOS_TOKEN_ID, PAD_TOKEN_ID = 0, 1, 2        # meshanything.py:102-
 def config_from_args(args) -> MAConfig:
     if isinstance(getattr(args, "ma_config", None), MAConfig):      # tests / tooling: an explicit shape (e.g. MAConfig.tiny())
         return args.ma_config
-    dtype = {"bf16": DTYPE_BF16, "fp32": DTYPE_F32}[getattr(args, "dtype", "bf16")]
+    dtype = {"bf16": DTYPE_BF16, "fp16": DTYPE_F16, "fp32": DTYPE_F32}[getattr(args, "dtype", "bf16")]
     return MAConfig.full(codebook_size=int(getattr(args, "codebook_size", 8192)), codebook_dim=int(getattr(args, "codebook_dim", 1024)),
                          n_max_faces=int(getattr(args, "n_max_triangles", 800)), max_batch=int(getattr(args, "batchsize_per_gpu", 1)),
                          dtype=dtype)

@@ -39,6 +39,7 @@ Device (`device`): "cpu" (default; what the CPU suite, the golden pins and bench
 
 Precision policy (`policy`):
   "fp32": no rounding anywhere -- the reference's CPU-equivalent arithmetic.
+  "fp16": the same rounding points with IEEE half (the engine's MA_DTYPE_F16 mode: the reference's own fp16-autocast arithmetic class).
   "bf16": mirrors the engine's MA_DTYPE_BF16 mode so that comparisons are like-for-like:
           every Linear computes fp32-accumulated dot products of bf16(x) and bf16(W);
           attention uses bf16(q), bf16(k), bf16(v) with fp32 scores/softmax/accumulation;
@@ -66,6 +67,14 @@ PAD_ID = -1                      # NoiseResistantDecoder.pad_id, meshanything.py
 def bf16r(x: torch.Tensor) -> torch.Tensor:
     """fp32 -> bf16 (round-to-nearest-even) -> fp32."""
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def fp16r(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> IEEE half (round-to-nearest-even, overflow to inf) -> fp32."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+ROUND16 = {"bf16": bf16r, "fp16": fp16r}
 
 
 def undiscretize(t: torch.Tensor, low: float, high: float, num_discrete: int) -> torch.Tensor:
@@ -129,7 +138,7 @@ def _api(fn):
 
 class Oracle:
     def __init__(self, cfg: MAConfig, state_dict: Dict[str, np.ndarray], policy: str = "fp32", device: str = "cpu"):
-        assert policy in ("fp32", "bf16")
+        assert policy in ("fp32", "bf16", "fp16")
         self.cfg = cfg
         self.policy = policy
         self.device = torch.device(device)
@@ -199,14 +208,14 @@ class Oracle:
             w = self.sd[name]
             if rows is not None:
                 w = w[rows]
-            if self.policy == "bf16":
-                w = bf16r(w)
+            if self.policy in ROUND16:
+                w = ROUND16[self.policy](w)
             self._wcache[key] = w = w.contiguous()
         return w
 
     def rin(self, x: torch.Tensor) -> torch.Tensor:
         """Rounding applied to a GEMM / attention input under the active policy."""
-        return bf16r(x) if self.policy == "bf16" else x
+        return ROUND16[self.policy](x) if self.policy in ROUND16 else x
 
     def linear(self, x: torch.Tensor, wname: str, bname: Optional[str] = None, rows: Optional[slice] = None) -> torch.Tensor:
         y = self.rin(x) @ self.W(wname, rows).t()
@@ -239,10 +248,10 @@ class Oracle:
                 qi = torch.arange(s, e, device=q.device)[:, None] + causal_offset
                 kj = torch.arange(Sk, device=q.device)[None, :]
                 w = w.masked_fill(kj > qi, float("-inf"))
-            if self.policy == "bf16" and dense:
+            if self.policy in ROUND16 and dense:
                 w = w.float()
                 pe = torch.exp(w - w.max(dim=-1, keepdim=True).values)
-                o = (bf16r(pe) @ vt) / pe.sum(dim=-1, keepdim=True)
+                o = (ROUND16[self.policy](pe) @ vt) / pe.sum(dim=-1, keepdim=True)
             else:
                 o = torch.softmax(w.float(), dim=-1) @ vt
             out[:, s:e] = o.permute(0, 2, 1, 3).reshape(B, e - s, H * D)

@@ -80,6 +80,7 @@ _ORDER = (
     ("test_gpu_rows_fused.py", ""),
     ("test_gpu_reference_anchor.py", ""),
     ("test_gpu_pipeline.py", "[bf16]"),
+    ("test_gpu_pipeline.py", "[fp16]"),
     ("test_gpu_pipeline.py", "test_v2_scale"),
     ("test_gpu_pipeline.py", "[fp32]"),
     ("test_gpu_fidelity.py", ""),
@@ -99,7 +100,7 @@ def _prio(item):
             if not is_full and not name.startswith(("test_large_batches", "test_weights_", "test_v2_scale")):
                 return i
             continue
-        if key in ("[bf16]", "[fp32]"):
+        if key in ("[bf16]", "[fp16]", "[fp32]"):
             if is_full and name.endswith(key):
                 return i
             continue
@@ -182,7 +183,7 @@ def load_weights_cached(engine, cfg, **kw):
     precision policy only -- not of max_batch or n_max_faces): 600 M parameters are converted once, not once per test module."""
     import torch
     from meshanything_amd.checkpoint import state_dict_spec
-    key = (cfg.dtype, tuple((k, v[0]) for k, v in state_dict_spec(cfg, False, False).items()), tuple(sorted(kw.items())))
+    key = (cfg.dtype, cfg.enc_exact, tuple((k, v[0]) for k, v in state_dict_spec(cfg, False, False).items()), tuple(sorted(kw.items())))
     arena = engine.arena_tensor()
     have = _ARENA_CACHE.get(key)
     if have is not None and have.numel() == arena.numel():

@@ -63,3 +63,42 @@ def test_half_precision_checkpoints_and_fused_bert_names(tmp_path):
     v = dp.pack_host_arena(cfg, ((k, (t.numpy() if hasattr(t, "numpy") else t)) for k, t in vanilla.items() if k in state_dict_spec(cfg)))
     assert np.array_equal(f, v)
     assert np.array_equal(bf16_round(np.float32([1.0, 1.00390625, 3.14159])), np.float32([1.0, 1.0, 3.140625]))
+
+
+def test_fp16_policy_arena_is_numpy_half_rounding():
+    """MA_DTYPE_F16: the host packer's fp32 -> half conversion (round to nearest even, subnormals, overflow to inf) against numpy's, bit for
+    bit, on every matrix entry of the arena plus the edge values; an fp16-STORED checkpoint (what the reference's fp16 run would save) packs
+    to the same bytes."""
+    import ctypes as C
+    from meshanything_amd import _lib
+    from meshanything_amd.config import DTYPE_F16
+    lib = _lib.load()
+    cfg = MAConfig.tiny(dtype=DTYPE_F16, enc_exact=0)
+    sd = synthetic_state_dict(cfg)
+    k = "transformer.lm_head.weight"
+    edge = np.array([0.0, -0.0, 1e-8, 5.9604645e-8, 2.98e-8, 6.1e-5, 6.0975552e-5, 65504.0, 65519.9, 65520.0, 1e6, -7e4, 1.0009766, 1.00048828125,
+                     1.00146484375, 3.1415927, -2.7182817, np.float32(2.0 ** -24), np.float32(2.0 ** -25), np.float32(1.5 * 2.0 ** -25)], dtype=np.float32)
+    w = sd[k].copy()
+    w.reshape(-1)[:edge.size] = edge
+    sd2 = dict(sd)
+    sd2[k] = w
+    arena = dp.pack_host_arena(cfg, sd2.items())
+    c = cfg.to_c()
+    name = C.create_string_buffer(256)
+    off, sz = C.c_int64(), C.c_int64()
+    dt, rows, cols = C.c_int32(), C.c_int32(), C.c_int32()
+    checked = 0
+    for i in range(lib.ma_arena_num_entries(C.byref(c))):
+        assert lib.ma_arena_entry(C.byref(c), i, name, 256, C.byref(off), C.byref(sz), C.byref(dt), C.byref(rows), C.byref(cols)) == 0
+        key = name.value.decode()
+        if dt.value != 2 or key not in sd2 or cols.value != sd2[key].shape[-1] or rows.value != sd2[key].shape[0]:
+            continue                                                  # fp32 entries; fused q/k/v and padded matrices (covered by the GPU suite)
+        got = arena[off.value:off.value + sz.value].view(np.uint16).reshape(rows.value, cols.value)
+        with np.errstate(over="ignore"):
+            want = sd2[key].astype(np.float16).view(np.uint16)
+        assert np.array_equal(got, want), key
+        checked += 1
+    assert checked >= 10
+    with np.errstate(over="ignore"):
+        stored = {kk: (v.astype(np.float16) if v.ndim == 2 and kk.endswith(("fc1.weight", "fc2.weight", "lm_head.weight")) else v) for kk, v in sd2.items()}
+    assert np.array_equal(dp.pack_host_arena(cfg, stored.items()), arena)

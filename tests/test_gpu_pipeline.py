@@ -6,15 +6,15 @@ import numpy as np
 import pytest
 import torch
 
-from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F32
+from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
 from conftest import cached_state_dict, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 
-POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16}
-# logit-margin below which a greedy disagreement is an ambiguous step (summation order / one bf16 rounding flip)
-GREEDY_TOL = {"fp32": 2e-4, "bf16": 2e-2}
+POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}
+# logit-margin below which a greedy disagreement is an ambiguous step (summation order / one 16-bit rounding flip)
+GREEDY_TOL = {"fp32": 2e-4, "bf16": 2e-2, "fp16": 3e-3}
 
 
 def synth_cloud(seed, n):
@@ -59,14 +59,14 @@ class Env:
         self.engine.load_weights(self.sd.items())
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "fp16"])
 def tiny(request):
     cfg = MAConfig.tiny(dtype=POLICIES[request.param], max_batch=4)
     return Env(cfg, request.param)
 
 
 def _tol(env, fp32, bf16):
-    return fp32 if env.policy == "fp32" else bf16
+    return fp32 if env.policy == "fp32" else (bf16 if env.policy == "bf16" else bf16 / 8)          # fp16: three more mantissa bits than bf16
 
 
 def test_encode_tiny(tiny):
@@ -186,7 +186,7 @@ def test_batched_mfma_decode_matches_oracle(tiny):
     """bf16 policy, batch >= 4: the decode step runs as skinny GEMMs on the matrix cores (different summation order than
     the batch-1 GEMV, so equality with batch-1 runs is not the criterion): every row must be a valid greedy / sampled
     decode of its own prefix under the oracle, with eos/pad semantics intact, deterministic, graph == eager."""
-    if tiny.policy != "bf16":
+    if tiny.policy == "fp32":
         pytest.skip("the fp32 policy has no MFMA decode path (row-parallel GEMV, covered above)")
     from oracle.meshanything_oracle import verify_sampled_stream
     x = clouds(tiny.cfg, [40, 41, 42, 43])
@@ -454,7 +454,7 @@ def assert_diverse(tokens, at_least, what=""):
     return n
 
 
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "fp16"])
 def full(request):
     from meshanything_amd.engine import Engine
     from oracle.meshanything_oracle import Oracle
@@ -498,7 +498,7 @@ def test_full_encode_and_detok_match_reference_golden(full, golden_dir):
         diff = torch.nan_to_num(coords, nan=9.0) != torch.nan_to_num(ref, nan=9.0)
         srt = torch.sort(logits, dim=-1, descending=True).values
         gap = (srt[..., 0] - srt[..., 1]).reshape(coords.shape)
-        print(f"[bf16] detokenizer: {int(diff.sum())} bins differ from the bf16-policy oracle; worst gap {float(gap[diff].max()) if diff.any() else 0:.3e}")
+        print(f"[{full.policy}] detokenizer: {int(diff.sum())} bins differ from the {full.policy}-policy oracle; worst gap {float(gap[diff].max()) if diff.any() else 0:.3e}")
         assert int(diff.sum()) <= 72 and (not diff.any() or float(gap[diff].max()) < 0.05)   # <= 1% of bins, near-ties only
 
 
@@ -540,7 +540,7 @@ def test_full_batched_generate_matches_oracle(full, golden_dir):
         full.engine.set_option("mfma_min_batch", 4)
         assert torch.equal(one[0], rowpar[0])
         same = int((rowpar == toks).all(dim=1).sum())
-        print(f"[bf16] MFMA batch path vs GEMV batch path: {same}/6 rows token-identical over {n} tokens")
+        print(f"[{full.policy}] MFMA batch path vs GEMV batch path: {same}/6 rows token-identical over {n} tokens")
         # the final-form attention (default from 8 rows on; 8 waves per (row, head) block below 12 rows) at the 350M shape
         full.engine.set_option("attn_final_min_batch", 4)
         fin, fin_len = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
@@ -549,7 +549,7 @@ def test_full_batched_generate_matches_oracle(full, golden_dir):
         assert all(r["ambiguous"] <= max(2, n // 12) for r in vf)
         same = int((fin == toks).all(dim=1).sum())
         # (on a diverse stream a near-tie that resolves differently forks the row for good: identity of whole rows is reported, not demanded)
-        print(f"[bf16] final-form vs split attention on the MFMA path: {same}/6 rows token-identical over {n} tokens")
+        print(f"[{full.policy}] final-form vs split attention on the MFMA path: {same}/6 rows token-identical over {n} tokens")
 
 
 def test_full_length_generation_properties(full, golden_dir):
@@ -566,7 +566,7 @@ def test_full_length_generation_properties(full, golden_dir):
     print(f"[{full.policy}] full-length stream: {nd} distinct ids in {cfg.max_new_tokens} tokens")
     again = full.engine.forward(x.cuda(), suppress_eos=True)
     assert torch.equal(toks, again["tokens"]) and torch.equal(torch.nan_to_num(out["coords"]), torch.nan_to_num(again["coords"]))
-    if full.policy == "bf16":
+    if full.policy != "fp32":
         full.engine.set_option("use_graph", 0)
         eager = full.engine.forward(x.cuda(), suppress_eos=True, max_new_tokens=600)
         full.engine.set_option("use_graph", 1)

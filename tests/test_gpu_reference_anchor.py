@@ -23,14 +23,14 @@ import pytest
 import torch
 
 from meshanything_amd.checkpoint import synthetic_state_dict
-from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F32
+from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
 from conftest import cached_state_dict, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
-POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16}
+POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}
 
 
-@pytest.mark.parametrize("policy", ["fp32", "bf16"])
+@pytest.mark.parametrize("policy", ["fp32", "bf16", "fp16"])
 def test_tokens_of_the_reference_shapeopt_under_hf_generate(policy, golden_dir):
     from meshanything_amd.engine import Engine
     from oracle.meshanything_oracle import Oracle, verify_greedy_stream
@@ -38,7 +38,7 @@ def test_tokens_of_the_reference_shapeopt_under_hf_generate(policy, golden_dir):
     cfg = MAConfig.tiny(dtype=POLICIES[policy], max_batch=4)
     sd = synthetic_state_dict(cfg)
     prefix = torch.from_numpy(g["gen_prefix"])
-    tol = {"fp32": 2e-4, "bf16": 2e-2}[policy]
+    tol = {"fp32": 2e-4, "bf16": 2e-2, "fp16": 3e-3}[policy]
 
     def check(sd_, want, **kw):
         eng = Engine(cfg)
@@ -128,11 +128,12 @@ def test_350m_logits_and_bins_against_the_reference_modules(policy, golden_dir):
 
 # ---- diverse streams: teacher-forced along the reference's path ---------------------------------------------------------------------------
 # bound = max abs logit error against the reference's fp32 numbers on ALL 257 steps of its path
-PATH_BOUND = {"fp32": 2e-3, "bf16": 8e-2}
+# (measured on MI355X, profiles/r04_*: fp32 1e-5, bf16 0.021, fp16 see the report)
+PATH_BOUND = {"fp32": 2e-3, "bf16": 8e-2, "fp16": 1e-2}
 
 
 @pytest.mark.parametrize("tag,init", [("dva", "diverse"), ("hfa", "hf")])
-@pytest.mark.parametrize("policy", ["bf16", "fp32"])
+@pytest.mark.parametrize("policy", ["bf16", "fp16", "fp32"])
 def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     from meshanything_amd.engine import Engine
     a = dict(np.load(os.path.join(golden_dir, "full_anchor_hf.npz")))
@@ -175,14 +176,24 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
           f"margin median {float(margin.median()):.4f}); engine's own {'draws' if sampled else 'picks'} equal the reference's tokens at {draw_equal * 100:.2f} % of the steps; "
           f"encoder latents err {e_lat:.3e}, prefix err {e_pre:.3e}")
     assert float(err.max()) <= bound, f"step {int(err.argmax())}: logits differ from the reference's by {float(err.max()):.4f}"
+    if policy == "fp16":
+        # the fixture's second set of numbers: the reference's OWN modules under torch.autocast(float16) along the same tokens -- the
+        # reference's real precision class (make_golden.py: golden_anchor_diverse).  Two fp16 implementations differ from each other by
+        # about what each differs from fp32.
+        err16 = torch.maximum((lg.gather(1, top_i) - torch.from_numpy(a[f"{tag}_f16_top_val"]).cuda()).abs().max(dim=1).values,
+                              (lg[:, cols] - torch.from_numpy(a[f"{tag}_f16_logits_cols"]).cuda()).abs().max(dim=1).values)
+        ref16 = torch.from_numpy(a[f"{tag}_f16_argmax"]).cuda()
+        print(f"[fp16/{tag}] against the reference under fp16 autocast: max abs logit error {float(err16.max()):.5f}, median {float(err16.median()):.5f}; "
+              f"argmax agreement {float((eng_arg == ref16).float().mean()) * 100:.2f} %")
+        assert float(err16.max()) <= 1.5e-2
     assert bool((eng_arg[decisive] == ref_arg[decisive]).all()), "argmax differs from the reference's at a decisive margin"
     if not sampled:
         assert torch.equal(picks, eng_arg), "the pick kernel's token is not the argmax of the logits it returned"
-        assert agree >= (0.999 if policy == "fp32" else 0.80)
+        assert agree >= {"fp32": 0.999, "fp16": 0.99, "bf16": 0.80}[policy]
     else:
         # the sampler on the reference's own context, with the reference's uniforms, against transformers' warpers: fp32 may differ where
         # a CDF edge or the top-p cut sits within rounding of the uniform; bf16 logits move the edges by a few 1e-2
-        assert draw_equal >= (0.97 if policy == "fp32" else 0.40), draw_equal
+        assert draw_equal >= {"fp32": 0.97, "fp16": 0.85, "bf16": 0.40}[policy], draw_equal
         assert int(picks.min()) >= 0 and not bool((picks == 1).any())
     assert e_lat < 1e-5 and e_pre < 1e-4                            # the encoder is exact under the bf16 policy too (cfg.enc_exact)
     # detokenizer on these weights: bins against the reference's wherever ITS margin is decisive
@@ -194,7 +205,7 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     bins = torch.round((coords[0].reshape(-1, 9) + 0.5) * cfg.discrete_num).long()
     ref_bins = torch.from_numpy(a[f"{tag}_detok_bins"]).long()
     dmargin = torch.from_numpy(a[f"{tag}_detok_margin"])
-    dbound = {"fp32": 2e-3, "bf16": 2.5e-2}[policy]
+    dbound = {"fp32": 2e-3, "bf16": 2.5e-2, "fp16": 5e-3}[policy]
     diff = (bins != ref_bins) & valid[:, None]
     print(f"[{policy}/{tag}] detokenizer: {int(diff.sum())} of {int(valid.sum()) * 9} bins differ; largest reference margin among them "
           f"{float(dmargin[diff].max()) if diff.any() else 0.0:.4f} (bound {2 * dbound})")
@@ -208,7 +219,7 @@ def test_forced_tokens_walk_the_given_stream_tiny():
     the oracle's teacher-forced distribution for that stream."""
     from meshanything_amd.engine import Engine
     from oracle.meshanything_oracle import Oracle
-    for policy, B in (("fp32", 1), ("fp32", 3), ("bf16", 1), ("bf16", 4)):
+    for policy, B in (("fp32", 1), ("fp32", 3), ("bf16", 1), ("bf16", 4), ("fp16", 2), ("fp16", 4)):
         cfg = MAConfig.tiny(dtype=POLICIES[policy], max_batch=4)
         sd = synthetic_state_dict(cfg)
         eng = Engine(cfg)
@@ -224,7 +235,7 @@ def test_forced_tokens_walk_the_given_stream_tiny():
         other[:, 0] = 0
         picks, lengths, lg = eng.generate(prefix.cuda(), suppress_eos=True, forced_tokens=other, return_logits=True)
         assert picks.shape == (B, n) and (lengths == n).all()
-        tol = {"fp32": 2e-4, "bf16": 3e-2}[policy]
+        tol = {"fp32": 2e-4, "bf16": 3e-2, "fp16": 4e-3}[policy]
         for b in range(B):
             ref = ora.teacher_forced_logits(prefix[b:b + 1], other[b])[:n]
             e = float((lg[b].cpu() - ref).abs().max())
