@@ -88,6 +88,9 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     };
     load_fc1();              // in the first instructions: requesting the fc1 rows under the exchange instead is 2 % slower (profiles/r02_ab_exchange_and_load_placement.txt)
     asm volatile("" ::: "memory");
+    // ... and nothing that CONSUMES a load may float up between them: hipcc's scheduler otherwise interleaves the merge arithmetic with the
+    // remaining requests (a wait per pair of loads: the fp16 instantiation did, 103 instead of 141 VGPRs and +1.3 us per launch, round 4)
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------
     {
@@ -129,6 +132,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         for (int i = 0; i < 8; ++i) w2[i] = ld_stream16(a.W2 + (size_t)orow * KF + (i * 64 + lane) * 8);
         e_b2 = a.b2[orow];
         asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
     // NSW waves per block sweep, each its own 1024 / NSW granules (16 / NSW per lane and pass).  The polling traffic is what costs (MI355X
     // guide): four waves that each polled ALL granules lost 1.2 %; four waves polling a quarter each win 4 % over one wave polling all

@@ -103,7 +103,9 @@ def test_gemv(lib, wdtype, N, K, variant):
                              _p(rd) if ln else None, _p(y), _p(xn) if ln else None, N, K, 1 if ln else 0, _stream()))
     torch.cuda.synchronize()
     assert not torch.isnan(y).any()
-    assert _relerr(y, ref) < 2e-5, _relerr(y, ref)
+    # (16-bit formats behind the LayerNorm prologue: an element that sits on a rounding boundary may round the other way than in the
+    #  reference's fp32 LayerNorm -- one ulp of one input element)
+    assert _relerr(y, ref) < (5e-5 if (ln and wdtype) else 2e-5), _relerr(y, ref)
     if ln:
         assert _relerr(xn, xr) < 1e-5
 
