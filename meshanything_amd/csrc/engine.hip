@@ -27,6 +27,7 @@
 #include "gemm.hpp"
 #include "gemm_decode.hpp"
 #include "gemm_tile.hpp"
+#include "gemm256.hpp"
 #include "gemv.hpp"
 #include "misc.hpp"
 #include "oproj_fc1.hpp"
@@ -257,7 +258,7 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
         t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
-        r = H16_CALL(e->hdt, HT, launch_gemm_tile<HT>(t, s));
+        r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s));
     } else {
         GemmArgs g{};
         g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
@@ -1426,6 +1427,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
+        else if (n == "gemm256") gemm256_enabled() = value ? 1 : 0;
         else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
         else if (n == "gemm_variant") {
 #ifndef MA_EXPERIMENTAL
@@ -1503,6 +1505,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "attn_impl") *value = e->opt_attn_impl;
         else if (n == "gemm_variant") *value = gemm_tile_variant();
+        else if (n == "gemm256") *value = gemm256_enabled();
         else throw MaError(MA_ERR_INVALID, "unknown option " + n);
     });
 }
@@ -1835,7 +1838,9 @@ int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
         if (!A || !W || (!C && !Cb)) throw MaError(MA_ERR_INVALID, "ma_op_gemm_bf16: null pointer");
         GemmTArgs t{reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), bias, R, ldr, C, ldc, reinterpret_cast<bf16_t*>(Cb), ldcb, M, N, K, act};
         t.xcd_swizzle = 1;
-        hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_tile<HT>(t, reinterpret_cast<hipStream_t>(stream)));
+        static int n_cus = -1;
+        if (n_cus < 0) { int dev = 0; hipDeviceProp_t prop; n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0; }
+        hipError_t r = H16_CALL(g_op_hdt, HT, launch_gemm_dense<HT>(t, n_cus, reinterpret_cast<hipStream_t>(stream)));
         if (r != hipSuccess) throw MaError(r == hipErrorInvalidValue ? MA_ERR_INVALID : MA_ERR_HIP, std::string("ma_op_gemm_bf16: ") + hipGetErrorString(r));
     });
 }

@@ -549,3 +549,68 @@ def test_gemm_bf16_tile(lib, h16, M, N, K, act, use_res, out, variant):
         print(f"[gemm_tile, variant {variant}] M {M} N {N} K {K} act {act} res {use_res} out {out}: {us:.1f} us = {2.0 * M * N * K / us * 1e-6:.1f} TFLOP/s")
     knob.set_option("gemm_variant", 6)
     knob.close()
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res,out", [(16448, 1024, 1024, 0, True, "f32"), (16448, 3072, 1024, 0, False, "bf16"), (16448, 4096, 1024, 1, False, "bf16"),
+                                                   (16448, 1024, 4096, 0, True, "f32"), (67648, 768, 768, 2, False, "both"), (8192, 8192, 512, 0, False, "bf16"),
+                                                   (4097, 4352, 128, 0, True, "both"), (33000, 1152, 768, 0, False, "f32"), (66000, 256, 64, 0, False, "f32")])
+def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
+    """The 256 x 256 x 64 eight-wave tile with the staged K-loop (csrc/gemm256.hpp) at the batched dense-phase shapes -- M = 64 x 257 (65 tile
+    rows: whole rounds on the big tile + the remainder on 128 x 128 tiles), M = 64 x 1057, ragged M and N edges, K = 64 (one K-tile: prologue only)
+    and K = 128 -- against fp64 torch; bit-stable across launches (its in-flight LDS-DMA schedule is timing dependent, its result must not be);
+    A/B timing against the 128-row tiles it replaces."""
+    from meshanything_amd.config import MAConfig, DTYPE_BF16
+    from meshanything_amd.engine import Engine
+    knob = Engine(MAConfig.tiny(dtype=DTYPE_BF16))                      # gemm256 is a process-wide knob behind an engine option
+    g = _gen(M + 3 * N + 5 * K)
+    A = (torch.randn(M, K, generator=g) + torch.linspace(-1, 1, K)[None, :] * 0.5).to(h16.tdt)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K) + torch.linspace(0, 1, N)[:, None] * 0.02).to(h16.tdt)
+    bias = torch.randn(N, generator=g) * 0.1
+    R = torch.randn(M, N, generator=g) if use_res else None
+    ref = A.double() @ W.double().t() + bias.double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = torch.nn.functional.gelu(ref)
+    if use_res:
+        ref = ref + R.double()
+    ref = ref.float()
+    scale = max(1e-6, float(ref.abs().max()))
+
+    def run(Cf, Cb):
+        _chk(lib, lib.ma_op_gemm_bf16(_p(A), K, _p(W), _p(bias), _p(R), N, _p(Cf), N, _p(Cb), N, M, N, K, act, _stream()))
+    res = {}
+    for mode in (1, 0, 1):
+        knob.set_option("gemm256", mode)
+        Cf = torch.full((M, N), float("nan")) if out in ("f32", "both") else None
+        Cb = torch.zeros(M, N, dtype=h16.tdt) if out in ("bf16", "both") else None
+        run(Cf, Cb)
+        torch.cuda.synchronize()
+        if Cf is not None:
+            assert not torch.isnan(Cf).any()
+            assert float((Cf - ref).abs().max()) / scale < 3e-5, (mode, float((Cf - ref).abs().max()) / scale)
+        if Cb is not None:
+            assert float((Cb.float() - ref).abs().max()) / scale < 6e-3
+            if Cf is not None:
+                assert torch.equal(Cb, Cf.to(h16.tdt))
+        if mode == 1 and 1 in res:
+            for a_, b_ in zip(res[1], (Cf, Cb)):
+                assert a_ is None or torch.equal(a_, b_), "the 256 x 256 kernel is not bit-stable from launch to launch"
+        res[mode] = (Cf, Cb)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(2):
+            run(Cf, Cb)
+        ev[0].record()
+        for _ in range(10):
+            run(Cf, Cb)
+        ev[1].record()
+        torch.cuda.synchronize()
+        res[("us", mode)] = ev[0].elapsed_time(ev[1]) / 10 * 1e3
+    # both kernels accumulate k-ascending in 32-wide MFMA steps: identical results, not just close ones
+    for a_, b_ in zip(res[0], res[1]):
+        assert a_ is None or torch.equal(a_, b_), "256 x 256 and 128-row tiles disagree bitwise"
+    fl = 2.0 * M * N * K
+    print(f"[gemm256 {h16.name}] M {M} N {N} K {K} act {act} res {use_res} out {out}: 256x256 {res[('us', 1)]:.1f} us = {fl / res[('us', 1)] * 1e-6:.1f} TFLOP/s | "
+          f"128-row tiles {res[('us', 0)]:.1f} us = {fl / res[('us', 0)] * 1e-6:.1f} TFLOP/s | ratio {res[('us', 0)] / res[('us', 1)]:.2f}x")
+    knob.set_option("gemm256", 1)
+    knob.close()
