@@ -107,7 +107,7 @@ def dense_phase_table(eng, cfg: MAConfig, batches=(16, 64), iters: int = 3):
 
 def measured_peaks(eng):
     """What THIS box reaches on the two roofline denominators, next to the vendor numbers the fractions are
-    quoted against: a 16-byte-per-lane streaming copy of 2 x 1 GiB (ma_op_stream_copy; read + write bytes) and the library's dense bf16
+    quoted against: a 16-byte-per-lane streaming copy of 2 x 1 GiB (ma_op_stream_copy, the fastest of its three forms; read + write bytes) and the library's dense bf16
     GEMM on 8192^3 uniform random [-1, 1) operands (ma_op_gemm_bf16)."""
     import ctypes as C
     lib = eng.lib
@@ -126,7 +126,7 @@ def measured_peaks(eng):
         ev[1].record()
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]) / reps * 1e-3
-    t_copy = timed(lambda: lib.ma_op_stream_copy(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), C.c_size_t(n), cur), 10)
+    t_copy = min(timed(lambda: lib.ma_op_stream_copy(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), C.c_size_t(n), mode, cur), 10) for mode in (0, 1, 2))
     del a, b
     M = 8192
     A = (torch.rand(M, M, device="cuda") * 2 - 1).to(torch.bfloat16)

@@ -281,9 +281,10 @@ MA_API int  ma_op_occupy_cus(int n_blocks, int lds_bytes, int64_t microseconds, 
  * IEEE half.  Per calling thread; parity tests run every 16-bit kernel in both formats.  No reference counterpart. */
 MA_API int  ma_op_set_half_dtype(int dtype);
 
-/* ---- measurement aid: dst[0, bytes) = src[0, bytes) as a 16-byte-per-lane streaming copy (2048 blocks, grid-stride); bytes % 16 == 0.  bench.py
- * times it to report the box's achievable HBM rate next to the 8 TB/s vendor number.  No reference counterpart. */
-MA_API int  ma_op_stream_copy(void *dst, const void *src, size_t bytes, void *stream);
+/* ---- measurement aid: dst[0, bytes) = src[0, bytes) as a 16-byte-per-lane streaming copy; bytes % 16 == 0; mode 0 = 2048 blocks grid-stride with
+ * non-temporal accesses, 1 = one element per thread with plain accesses, 2 = one element per thread non-temporal.  bench.py times all three and
+ * reports the box's achievable HBM rate next to the 8 TB/s vendor number.  No reference counterpart. */
+MA_API int  ma_op_stream_copy(void *dst, const void *src, size_t bytes, int mode, void *stream);
 
 /* ---- persistent decode step (csrc/persist.hpp; only in libraries built with MA_EXPERIMENTAL=1 -- measured 1.3-1.6x slower than the launch
  * chain; the product build answers MA_ERR_STATE / 0): the whole batch-1 greedy step as ONE resident launch instead of the

@@ -89,7 +89,7 @@ SIGNATURES = {
     "ma_op_gemm_dec_qkv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_size_t, _P]),
     "ma_op_rows_prologue": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _P]),
     "ma_op_occupy_cus": (_I, [_I, _I, C.c_int64, _P, _P]),
-    "ma_op_stream_copy": (_I, [_P, _P, C.c_size_t, _P]),
+    "ma_op_stream_copy": (_I, [_P, _P, C.c_size_t, _I, _P]),
     "ma_op_set_half_dtype": (_I, [_I]),
     "ma_engine_persist_available": (_I, [_P]),
     "ma_persist_trace": (_I, [_P, _I, _P, C.POINTER(C.c_int32), _P]),

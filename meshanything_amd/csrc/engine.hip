@@ -1999,11 +1999,15 @@ int ma_op_set_half_dtype(int dtype) {
     return MA_OK;
 }
 
-int ma_op_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
+int ma_op_stream_copy(void* dst, const void* src, size_t bytes, int mode, void* stream) {
     return guarded(nullptr, [&] {
-        if (!dst || !src || bytes % 16) throw MaError(MA_ERR_INVALID, "ma_op_stream_copy: null pointer or size not a multiple of 16");
-        hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const u32x4*>(src),
-                           reinterpret_cast<u32x4*>(dst), bytes / 16);
+        if (!dst || !src || bytes % 16 || mode < 0 || mode > 2) throw MaError(MA_ERR_INVALID, "ma_op_stream_copy: null pointer, size not a multiple of 16 or mode outside 0 .. 2");
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        const size_t n16 = bytes / 16;
+        const u32x4* sp = reinterpret_cast<const u32x4*>(src); u32x4* dp = reinterpret_cast<u32x4*>(dst);
+        if (mode == 0) hipLaunchKernelGGL(stream_copy_kernel<0>, dim3(2048), dim3(256), 0, s, sp, dp, n16);
+        else if (mode == 1) hipLaunchKernelGGL(stream_copy_kernel<1>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, sp, dp, n16);
+        else hipLaunchKernelGGL(stream_copy_kernel<2>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, sp, dp, n16);
         HIP_CHECK(hipGetLastError());
     });
 }

@@ -2,7 +2,7 @@
 // tile, 8 waves, with the staged "8-phase" K-loop of the MI355X guide (section 5, "The 256^2 8-phase template"; T2-T5).
 //
 // Same reference call sites, operands, epilogue and accumulation order (k ascending in 32-wide MFMA steps) as gemm_tile.hpp, whose
-// 128 x 128 tile stays the kernel of the small problems and of the remainder tiles (see launch_gemm256).  Why a second kernel: the 128-row
+// 128 x 128 tile stays the kernel of the small and oddly sized problems (see launch_gemm_dense).  Why a second kernel: the 128-row
 // tile needs 62 B/clk/CU of LDS fill per MFMA-bound cycle and stalls on its one barrier per K-tile (15-18 % of the
 // bf16 MFMA peak in the pipeline); a 256 x 256 tile halves the fill per FLOP, and the phase structure below keeps LDS reads, LDS-DMA and
 // MFMAs of the two wave groups overlapped.
@@ -28,9 +28,10 @@
 //   * the two wave groups (waves 0-3 / 4-7 = wave rows 0 / 1, which share the four SIMDs pairwise) run staggered by ONE barrier: while
 //     one group issues MFMAs the other reads LDS and issues DMA -- the role split that s_setprio(1) around the MFMA cluster arbitrates.
 // Epilogue as gemm_tile.hpp (bias, ReLU / GELU, fp32 residual, fp32 and / or 16-bit output through the row map).
-// Algorithmic FLOPs: 2 M N K.  Tiles are handed out XCD-aware (consecutive tiles of the (m, n) list on one XCD).
+// Algorithmic FLOPs: 2 M N K.  Tiles are handed out XCD-aware (an 8 x 4 patch of tiles per XCD at a time: see the kernel).
 #pragma once
 #include "common.hpp"
+#include "gemm_decode.hpp"
 #include "gemm_tile.hpp"
 
 namespace ma {
@@ -40,10 +41,13 @@ constexpr int G256_LDS = 2 * 4 * G256_PIECE;       // two K-tile buffers x {X_0,
 
 template <int N> __device__ __forceinline__ void g256_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-// tile_lo: first tile (of the (m, n) tile list, n fastest) this launch computes; it computes gridDim.x of them
+// The launch computes the nty x ntx tiles of rows [0, 256 nty).  Tile order: column panels of four n-tiles, m fastest inside a panel, so that
+// the 32 tiles an XCD works on at a time form an 8 (m) x 4 (n) patch -- 12 operand tiles through its L2 instead of 2 + 16 (or 1 + 32) with
+// the n-fastest list.
 // ACT: the activation is a template parameter here (128 accumulators x an inlined erf would otherwise sit in every instantiation)
-template <typename HT, int ACT>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, int ntx) {
+// ABL (scripts/ubench_gemm256.hip only; 0 in the library): ablation bits -- 1 no LDS-DMA in the loop, 2 no ds_reads, 4 no MFMAs, 8 no stores
+template <typename HT, int ACT, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char g256_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
     // XCD-aware hand-out: workgroups go to the XCDs round-robin; XCD i works on the i-th eighth of this launch's tile range
@@ -52,8 +56,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
         const int tiles = gridDim.x, xcd = t & 7, i = t >> 3, lo = tiles >> 3, rem = tiles & 7;
         t = xcd * lo + min(xcd, rem) + i;
     }
-    t += tile_lo;
-    const int tile_y = t / ntx, tile_x = t - tile_y * ntx;
+    int tile_y, tile_x;
+    {
+        const int fullp = ntx >> 2, tailw = ntx & 3, cut = fullp * 4 * nty;
+        if (t < cut) { const int p = t / (4 * nty), r = t - p * 4 * nty; tile_y = r >> 2; tile_x = p * 4 + (r & 3); }
+        else { const int r = t - cut; tile_y = r / tailw; tile_x = fullp * 4 + r - tile_y * tailw; }
+    }
     const int bm = tile_y * 256, bn = tile_x * 256;
     const unsigned lds0 = (unsigned)(size_t)g256_smem;
     const int nk = g.K >> 6;
@@ -73,11 +81,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
             wsrc[s][i] = g.W + (size_t)n * g.K + sw;
         }
     auto stage_x = [&](int s, int kt) {
+        if constexpr (ABL & 1) { if (kt > 0) return; }
         const unsigned dst = lds0 + (unsigned)(kt & 1) * (4u * G256_PIECE) + (unsigned)s * G256_PIECE + (unsigned)w * 1024u;
         gt_glds16(xsrc[s][0] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst));
         gt_glds16(xsrc[s][1] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst + 8192u));
     };
     auto stage_w = [&](int s, int kt) {
+        if constexpr (ABL & 1) { if (kt > 0) return; }
         const unsigned dst = lds0 + (unsigned)(kt & 1) * (4u * G256_PIECE) + (unsigned)(2 + s) * G256_PIECE + (unsigned)w * 1024u;
         gt_glds16(wsrc[s][0] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst));
         gt_glds16(wsrc[s][1] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst + 8192u));
@@ -107,6 +117,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
                 for (int j = 0; j < 4; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 xf[4][2], wf[2][2];
     auto read_x = [&](int s, int kt) {
+        if constexpr (ABL & 2) { if (kt > 0) return; }
         const char* base = g256_smem + (kt & 1) * (4 * G256_PIECE) + s * G256_PIECE;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
             for (int ks = 0; ks < 2; ++ks) xf[j][ks] = *reinterpret_cast<const u32x4*>(base + xoff[j][ks]);
     };
     auto read_w = [&](int s, int kt) {
+        if constexpr (ABL & 2) { if (kt > 0) return; }
         const char* base = g256_smem + (kt & 1) * (4 * G256_PIECE) + (2 + s) * G256_PIECE;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                           \
+        if (!(ABL & 4) || kt == 0)                                                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
     // ---- prologue: K-tile 0 complete, the first two pieces of K-tile 1 ---------------------------------------------------------------------
     stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
     if (nk > 1) { stage_x(0, 1); stage_w(1, 1); g256_wait_vm<4>(); } else g256_wait_vm<0>();
+    if (trace && tid == 0) trace[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                       // the second wave group runs one barrier behind the first
 
@@ -162,93 +176,165 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int tile_lo, 
         G256_COMPUTE(1, 0);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                       // (the barrier the first group is ahead by)
+    if (trace && tid == 0) trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #undef G256_COMPUTE
 
-    // ---- epilogue: lane holds n = n0 .. n0 + 3 of row m (gemm_tile.hpp's) --------------------------------------------------------------------
+    // ---- epilogue ----------------------------------------------------------------------------------------------------------------------------
+    // A lane holds n = n0 .. n0 + 3 of 32 rows: stored from registers that is 32 narrow stores per lane into 64-byte row segments, and with ONE
+    // block per CU nothing overlaps them -- measured 11.7 us per tile, as long as the whole K-loop at K = 512 (store-issue bound, guide T21).
+    // Instead every wave parks its 128 x 64 sub-tile in its own 16 KB of the (now free) LDS -- bias and activation applied, 16-byte chunks
+    // XOR-swizzled by the row -- and streams it out as whole row segments with 16-byte stores: 128 B (16-bit output: 8 rows per instruction) or
+    // 256 B (fp32 output, 64 rows at a time: 4 rows per instruction); the fp32 residual is read the same way.  Only this wave touches its
+    // region, so the hand-over is an lgkmcnt(0), not a barrier (every wave has passed the K-loop's last barrier: no one reads operands any more).
+    char* patch = g256_smem + w * 16384;
+    f32x4 bias4[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int n0 = bn + wn * 64 + b * 32 + i * 16 + kg * 4;
-            if (n0 >= g.N) continue;
-            const bool full = n0 + 3 < g.N;
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (g.bias) {
-                if (full) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0);
-                else { b4.x = g.bias[n0]; if (n0 + 1 < g.N) b4.y = g.bias[n0 + 1]; if (n0 + 2 < g.N) b4.z = g.bias[n0 + 2]; }
+                if (n0 + 3 < g.N) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0);
+                else { if (n0 < g.N) b4.x = g.bias[n0]; if (n0 + 1 < g.N) b4.y = g.bias[n0 + 1]; if (n0 + 2 < g.N) b4.z = g.bias[n0 + 2]; }
             }
+            bias4[b][i] = b4;
+        }
+    const int nw0 = bn + wn * 64;                                    // first column of this wave's sub-tile
+    if (g.C == nullptr) {
+        // 16-bit output only: patch rows of 128 B (64 elements), chunk = 8 elements
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = bm + wm * 128 + a * 64 + j * 16 + fr;
-                    if (m >= g.M) continue;
-                    const size_t mr = (size_t)(g.r_mod > 0 ? m % g.r_mod : m), mo = g.cmap(m);
-                    f32x4 v = acc[a][b][i][j];
-                    v.x = apply_act(v.x + b4.x, ACT); v.y = apply_act(v.y + b4.y, ACT);
-                    v.z = apply_act(v.z + b4.z, ACT); v.w = apply_act(v.w + b4.w, ACT);
-                    if (full) {
-                        if (g.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(g.R + mr * g.ldr + n0); v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-                        if (g.C) *reinterpret_cast<f32x4*>(g.C + mo * g.ldc + n0) = v;
-                        if (g.Cb) *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + n0) = pack4<HT>(v);
-                    } else {
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-                        for (int r = 0; r < 4 && n0 + r < g.N; ++r) {
-                            float tt = vv[r];
-                            if (g.R) tt += g.R[mr * g.ldr + n0 + r];
-                            if (g.C) g.C[mo * g.ldc + n0 + r] = tt;
-                            if (g.Cb) g.Cb[mo * g.ldcb + n0 + r] = H16<HT>::bits(tt);
-                        }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 v = acc[a][b][i][j];
+                        const f32x4 b4 = bias4[b][i];
+                        v.x = apply_act(v.x + b4.x, ACT); v.y = apply_act(v.y + b4.y, ACT); v.z = apply_act(v.z + b4.z, ACT); v.w = apply_act(v.w + b4.w, ACT);
+                        const int rr = a * 64 + j * 16 + fr, chunk = b * 4 + i * 2 + (kg >> 1);
+                        *reinterpret_cast<u32x2*>(patch + rr * 128 + ((chunk ^ (rr & 7)) * 16) + (kg & 1) * 8) = pack4<HT>(v);
+                    }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int r8 = lane >> 3, c = lane & 7, ncol = nw0 + c * 8;
+        if constexpr (!(ABL & 8)) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + r8, m = bm + wm * 128 + row;
+            if (m >= g.M || ncol >= g.N) continue;
+            const u32x4 q = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
+            bf16_t* dst = g.Cb + g.cmap(m) * g.ldcb + ncol;
+            if (ncol + 7 < g.N) *reinterpret_cast<u32x4*>(dst) = q;
+            else { const bf16_t* e = reinterpret_cast<const bf16_t*>(&q); for (int r = 0; r < 8 && ncol + r < g.N; ++r) dst[r] = e[r]; }
+        }
+        }
+    } else {
+        // fp32 output (+ residual, + optional 16-bit copy): 64 rows at a time, patch rows of 256 B (64 floats), chunk = 4 floats
+        const int r4 = lane >> 4, c = lane & 15, ncol = nw0 + c * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f32x4 v = acc[a][b][i][j];
+                        const f32x4 b4 = bias4[b][i];
+                        v.x = apply_act(v.x + b4.x, ACT); v.y = apply_act(v.y + b4.y, ACT); v.z = apply_act(v.z + b4.z, ACT); v.w = apply_act(v.w + b4.w, ACT);
+                        const int rr = j * 16 + fr, chunk = b * 8 + i * 4 + kg;
+                        *reinterpret_cast<f32x4*>(patch + rr * 256 + ((chunk ^ (rr & 15)) * 16)) = v;
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(ABL & 8)) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + r4, m = bm + wm * 128 + a * 64 + row;
+                if (m >= g.M || ncol >= g.N) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
+                const size_t mr = (size_t)(g.r_mod > 0 ? m % g.r_mod : m), mo = g.cmap(m);
+                if (ncol + 3 < g.N) {
+                    if (g.R) { const f32x4 r4v = *reinterpret_cast<const f32x4*>(g.R + mr * g.ldr + ncol); v.x += r4v.x; v.y += r4v.y; v.z += r4v.z; v.w += r4v.w; }
+                    *reinterpret_cast<f32x4*>(g.C + mo * g.ldc + ncol) = v;
+                    if (g.Cb) *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + ncol) = pack4<HT>(v);
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int r = 0; r < 4 && ncol + r < g.N; ++r) {
+                        float tt = vv[r];
+                        if (g.R) tt += g.R[mr * g.ldr + ncol + r];
+                        g.C[mo * g.ldc + ncol + r] = tt;
+                        if (g.Cb) g.Cb[mo * g.ldcb + ncol + r] = H16<HT>::bits(tt);
                     }
                 }
+            }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the patch is re-written for the second half
         }
+    }
+    if (trace && tid == 0) trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
-// Whole rounds of the chip (one block per CU) run on the 256 x 256 tile; what is left of the tile list -- M = B x 257 gives 65 x N / 256
-// tiles, a little more than a multiple of the CU count -- is covered by the 128 x 128 tile (four per big tile, lin_* mapping of
-// gemm_tile.hpp), so the tail costs a quarter-tile's time on a few CUs instead of a whole extra round on all of them.
 template <typename HT, int ACT>
-inline hipError_t g256_launch(const GemmTArgs& g, int tiles, int ntx, hipStream_t s) {
+inline hipError_t g256_launch(const GemmTArgs& g, int nty, int ntx, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<HT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<HT, ACT>), dim3(tiles), dim3(512), G256_LDS, s, g, 0, ntx);
+    hipLaunchKernelGGL((gemm256_kernel<HT, ACT>), dim3(nty * ntx), dim3(512), G256_LDS, s, g, nty, ntx, (unsigned long long*)nullptr);
     return hipGetLastError();
-}
-
-template <typename HT>
-inline hipError_t launch_gemm256(const GemmTArgs& g, int n_cus, hipStream_t s) {
-    const int ntx = (g.N + 255) / 256, nty = (g.M + 255) / 256, tiles = ntx * nty;
-    const int full = n_cus > 0 ? tiles / n_cus * n_cus : tiles;
-    // a remainder of more than 3/4 of a round runs as one more round of big tiles (the small tile would take longer than that round)
-    const int big = (tiles - full) * 4 > 3 * n_cus ? tiles : full;
-    if (big > 0) {
-        hipError_t r = g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(g, big, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(g, big, ntx, s) : g256_launch<HT, ACT_NONE>(g, big, ntx, s);
-        if (r != hipSuccess) return r;
-    }
-    if (big < tiles) {
-        GemmTArgs t = g;
-        t.lin_t0 = big; t.lin_ntx = ntx; t.lin_tiles = tiles - big;
-        return gt_launch_lin<HT>(t, s);
-    }
-    return hipSuccess;
 }
 
 // engine option "gemm256" (default 1): A/B switch between this kernel and the 128-row tiles for the shapes it covers
 inline int& gemm256_enabled() { static int v = 1; return v; }
 
-// the dense GEMM of the 16-bit policies: the 256 x 256 kernel where the problem fills at least one round of the chip with its tiles,
-// the tiles of gemm_tile.hpp otherwise (small M of batch-1 runs, N = 64 / 128 projections, K not a multiple of 64)
+// The dense GEMM of the 16-bit policies.  The big tile wants WHOLE rounds of the chip (one block per CU): the matrix is cut along M into
+//   * the leading tile rows whose tiles fill the rounds to within 12 % -- all whole tile rows when that holds (M = 64 x 257: 64 rows of 4 / 12 /
+//     16 tiles = 1 / 3 / 4 rounds), else the largest count that makes exact rounds (M = 64 x 1057, N = 768: 256 of the 264 tile rows x 3 tiles);
+//   * the rest: a tail of <= 64 rows (M = B x 257 and B x 1057 leave 64 at B = 64) goes to the skinny matrix-core GEMM of the batched decode
+//     step (gemm_decode.hpp: 16 weight rows per block, the tail's rows as the B operand); anything larger to the tiles of gemm_tile.hpp.
+// Problems that do not give the big tile one full round (small M of batch-1 runs, N = 64 / 128 projections, K not a multiple of 64) stay on
+// gemm_tile.hpp entirely.  Outputs through a row map / a broadcast residual are not split (the encoder's, fp32 under enc_exact anyway).
+inline int g256_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
 template <typename HT>
 inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
-    const long tiles = (long)((g.N + 255) / 256) * ((g.M + 255) / 256);
-    if (gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && tiles >= n_cus && tiles < (1L << 24))
-        return launch_gemm256<HT>(g, n_cus, s);
+    if (gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && (long)((g.N + 255) / 256) * ((g.M + 255) / 256) < (1L << 24)) {
+        const int ntx = (g.N + 255) / 256;
+        const bool can_split = g.cmap.grp == 0 && g.r_mod == 0;
+        auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles >= n_cus && tiles * 100 >= rounds * n_cus * 88; };
+        int nty = 0;                                                 // tile rows on the big tile
+        if (!can_split) { if (fills((long)ntx * ((g.M + 255) / 256))) nty = (g.M + 255) / 256; }      // ragged last tile row computed with clamped rows
+        else if (fills((long)ntx * (g.M / 256))) nty = g.M / 256;
+        else { const int q = n_cus / g256_gcd(ntx, n_cus); nty = g.M / 256 / q * q; }
+        if (nty > 0) {
+            GemmTArgs m = g;
+            m.M = can_split ? nty * 256 : g.M;
+            hipError_t r = g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s);
+            const int rest = can_split ? g.M - nty * 256 : 0;
+            if (r != hipSuccess || rest == 0) return r;
+            const size_t r0 = (size_t)nty * 256;
+            if (rest <= 64 && g.K % 128 == 0) {
+                GemmDecArgs d{};
+                d.W = g.W; d.bias = g.bias; d.xb = g.A + r0 * g.lda; d.xb_stride = g.lda; d.N = g.N; d.K = g.K; d.B = rest; d.act = g.act; d.epi = EPI_PLAIN; d.ksplit = 1;
+                if (g.R) { d.res = g.R + r0 * g.ldr; d.res_stride = g.ldr; }
+                if (g.C) { d.y = g.C + r0 * g.ldc; d.y_stride = g.ldc; }
+                if (g.Cb) { d.yb = g.Cb + r0 * g.ldcb; d.yb_stride = g.ldcb; }
+                return launch_gemm_dec<HT>(d, s);
+            }
+            GemmTArgs t = g;
+            t.A = g.A + r0 * g.lda; t.M = rest;
+            if (g.R) t.R = g.R + r0 * g.ldr;
+            if (g.C) t.C = g.C + r0 * g.ldc;
+            if (g.Cb) t.Cb = g.Cb + r0 * g.ldcb;
+            return launch_gemm_tile<HT>(t, s);
+        }
+    }
     return launch_gemm_tile<HT>(g, s);
 }
 

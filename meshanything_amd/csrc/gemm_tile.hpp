@@ -38,9 +38,6 @@ struct GemmTArgs {
     int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
     RowMap cmap;                    // output row of logical row m
     int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
-    // remainder mode (gemm256.hpp): the launch covers the 256 x 256 tiles lin_t0 .. lin_t0 + lin_tiles - 1 of an (m, n) tile list with lin_ntx
-    // tiles per row, four 128 x 128 blocks per tile; 0 = the plain rectangular grid
-    int lin_t0, lin_ntx, lin_tiles;
 };
 
 __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
@@ -85,12 +82,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
         const int t = xcd * lo + min(xcd, rem) + i;
         tile_y = t / NT; tile_x = t - tile_y * NT;
     }
-    int bm = tile_y * BM, bn = tile_x * BN;
-    if (g.lin_ntx > 0) {
-        const int big = g.lin_t0 + (int)blockIdx.x / 4, sub = blockIdx.x & 3;
-        bm = (big / g.lin_ntx) * 256 + (sub >> 1) * 128; bn = (big % g.lin_ntx) * 256 + (sub & 1) * 128;
-        if (bm >= g.M || bn >= g.N) return;                     // a quarter that lies wholly outside a ragged edge
-    }
+    const int bm = tile_y * BM, bn = tile_x * BN;
     const unsigned lds0 = (unsigned)(size_t)gt_smem;
 
     // ---- DMA addressing: instruction p of an operand covers tile rows p * RPI .. + RPI - 1; lane -> (row, slot) -----------
@@ -212,22 +204,6 @@ inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
         attr = true;
     }
     hipLaunchKernelGGL((gemm_tile_kernel<HT, BM, BN, BK, NS, RAW, WM, WN>), dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM), dim3(WM * WN * 64), LDS, s, g);
-    return hipGetLastError();
-}
-
-// the remainder launch of gemm256.hpp: lin_tiles big tiles as four 128 x 128 blocks each
-template <typename HT>
-inline hipError_t gt_launch_lin(const GemmTArgs& g, hipStream_t s) {
-    constexpr int LDS = 2 * (128 + 128) * 64 * 2;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<HT, 128, 128, 64, 2, true, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (r != hipSuccess) return r;
-        attr = true;
-    }
-    GemmTArgs t = g;
-    t.xcd_swizzle = 0;
-    hipLaunchKernelGGL((gemm_tile_kernel<HT, 128, 128, 64, 2, true, 2, 2>), dim3(4 * g.lin_tiles), dim3(256), LDS, s, t);
     return hipGetLastError();
 }
 

@@ -68,6 +68,11 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         const int k = tid * 4;
         attn_partials_load(ws, a.heads, k >> 6, k & 63, pml, po);
     }
+    // fp16 instantiation: the 24 requests of the partials go out together, ahead of everything else -- hipcc interleaved them pairwise with
+    // the merge arithmetic there (a wait per pair: +1.3 us per launch, 10.28 -> 9.58 us with this pin).  The bf16 instantiation keeps the
+    // schedule the compiler gives it (measured best since round 2); forcing ALL requests, weights included, in front of the merge was 9 %
+    // slower in both formats (profiles/r04_ab_load_pinning.txt).
+    if constexpr (__is_same(HT, f16_t)) __builtin_amdgcn_sched_barrier(0);
     const int orow = 4 * b + w;                          // out_proj row of this wave
     u32x4 wo[2];
 #pragma unroll
@@ -88,9 +93,6 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     };
     load_fc1();              // in the first instructions: requesting the fc1 rows under the exchange instead is 2 % slower (profiles/r02_ab_exchange_and_load_placement.txt)
     asm volatile("" ::: "memory");
-    // ... and nothing that CONSUMES a load may float up between them: hipcc's scheduler otherwise interleaves the merge arithmetic with the
-    // remaining requests (a wait per pair of loads: the fp16 instantiation did, 103 instead of 141 VGPRs and +1.3 us per launch, round 4)
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- (2) out_proj: gemv_kernel<bf16_t, 1, 2, 1, PRO_ATTN> ------------------------------------------------------------------------
     {
@@ -132,7 +134,6 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         for (int i = 0; i < 8; ++i) w2[i] = ld_stream16(a.W2 + (size_t)orow * KF + (i * 64 + lane) * 8);
         e_b2 = a.b2[orow];
         asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
     }
     // NSW waves per block sweep, each its own 1024 / NSW granules (16 / NSW per lane and pass).  The polling traffic is what costs (MI355X
     // guide): four waves that each polled ALL granules lost 1.2 %; four waves polling a quarter each win 4 % over one wave polling all

@@ -107,7 +107,6 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
         for (int u = 0; u < G::U; ++u) { const int p = base + u * G::PPW; vr[u] = ld_stream16(vh + (size_t)(p < end ? p : start) * 64); }
     };
     asm volatile("" ::: "memory");                       // pin the weight / bias loads HERE
-    __builtin_amdgcn_sched_barrier(0);                   // (and keep their consumers below them: see oproj_fc1.hpp)
 
     // ---- (2) prologue + dot products: gemv_kernel<bf16_t, 1, 2, *, PRO> for the rows of this block --------------------------------
     if constexpr (PRO == PRO_LN) ln_block_onepass<1>(xv, gv, bv, x0, tid, KC / 4, KC, a.ln_eps, red);
@@ -149,7 +148,6 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     // second round in flight buys nothing: profiles/r02_ab_exchange_and_load_placement.txt)
     if (nround > 0) issue(0, kA, vA);
     asm volatile("" ::: "memory");                       // pin them HERE (hipcc would sink them below the sweep)
-    __builtin_amdgcn_sched_barrier(0);
     if (w == 0) {
         const gu64* g64 = (const gu64*)gran;
         const int nparts = c == c_last ? 3 : 1;          // q for everyone; k, v for the block that holds the newest position

@@ -606,9 +606,11 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
         ev[1].record()
         torch.cuda.synchronize()
         res[("us", mode)] = ev[0].elapsed_time(ev[1]) / 10 * 1e3
-    # both kernels accumulate k-ascending in 32-wide MFMA steps: identical results, not just close ones
+    # both tile kernels accumulate k-ascending in 32-wide MFMA steps: identical results, not just close ones -- on the rows the big tile
+    # computes (a tail of <= 64 rows goes to the skinny GEMM of the batched decode step, whose four waves split K)
+    same_rows = M - (M % 256 if M % 256 <= 64 else 0)
     for a_, b_ in zip(res[0], res[1]):
-        assert a_ is None or torch.equal(a_, b_), "256 x 256 and 128-row tiles disagree bitwise"
+        assert a_ is None or torch.equal(a_[:same_rows], b_[:same_rows]), "256 x 256 and 128-row tiles disagree bitwise"
     fl = 2.0 * M * N * K
     print(f"[gemm256 {h16.name}] M {M} N {N} K {K} act {act} res {use_res} out {out}: 256x256 {res[('us', 1)]:.1f} us = {fl / res[('us', 1)] * 1e-6:.1f} TFLOP/s | "
           f"128-row tiles {res[('us', 0)]:.1f} us = {fl / res[('us', 0)] * 1e-6:.1f} TFLOP/s | ratio {res[('us', 0)] / res[('us', 1)]:.2f}x")
