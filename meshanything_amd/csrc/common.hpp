@@ -265,12 +265,13 @@ __device__ __forceinline__ void xchg_raise(unsigned* err, unsigned code) {
     __hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// diagnostics of the fused launches (a 20-30 ms dispatch per profiled run that is NOT a sweep time-out): a block whose
-// life from its first instruction to the end of its last exchange exceeds 1 ms counts itself in err[3] and leaves the longest such span
-// (100 MHz ticks) in err[2]; ma_engine_get_option("slow_blocks" / "slow_block_max_us") and the bench line report them.  Two scalar
-// clock reads per block, off the critical path.
-__device__ __forceinline__ void xchg_note_slow(unsigned* err, u64 t_start) {
-    const u64 dt = __builtin_amdgcn_s_memrealtime() - t_start;
+// diagnostics of the fused launches (a 20-30 ms dispatch per profiled run that is NOT a sweep time-out): a sweep that
+// needed more than 256 polls leaves its duration (100 MHz ticks since its start) in err[2] if it exceeded 1 ms and counts itself in err[3];
+// ma_engine_get_option("slow_blocks" / "slow_block_max_us") and the bench line report them.  Nothing on the normal path: the poll count is
+// in a register, the clock is read only behind the branch.
+__device__ __forceinline__ void xchg_note_slow(unsigned* err, unsigned spins, u64 t0) {
+    if (spins <= 256u) return;
+    const u64 dt = __builtin_amdgcn_s_memrealtime() - t0;
     if (dt > 100000ull) {
         __hip_atomic_fetch_max(err + 2, (unsigned)(dt > 0xffffffffull ? 0xffffffffull : dt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(err + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -57,7 +57,6 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     __shared__ __attribute__((aligned(16))) float yraw[KC];
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const u64 t_block = __builtin_amdgcn_s_memrealtime();
     if (a.trace && tid == 0) a.trace[b * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const float* ws = a.attn_ws + (size_t)brow * attn_workspace_floats(a.heads);
     const unsigned epoch = (unsigned)a.st[brow].pos * 32u + (unsigned)a.layer + 1u;
@@ -168,6 +167,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 break;
             }
         }
+        if (lane == 0) xchg_note_slow(a.err, spins, t0);
     }
     __syncthreads();
     if (a.trace && tid == 0) a.trace[b * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -252,9 +252,9 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                     break;
                 }
             }
+            if (lane == 0) xchg_note_slow(a.err, spins, t0);
         }
         __syncthreads();
-        if (tid == 0) xchg_note_slow(a.err, t_block);
         if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
         // ---- (6) fc2: gemv_kernel<bf16_t, 1, 8, 1, PRO_PLAIN>, row 4b + w ---------------------------------------------------------------
         float acc = 0.f;

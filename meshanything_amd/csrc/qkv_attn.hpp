@@ -75,7 +75,6 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     __shared__ AttnMergeLds<HT> S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Hd = a.hidden;
-    const u64 t_block = __builtin_amdgcn_s_memrealtime();
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const float* x = a.x + (size_t)brow * a.x_stride;
     const DecState sv = a.st[brow];
@@ -175,6 +174,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
                 break;
             }
         }
+        if (lane == 0) xchg_note_slow(a.err, spins, t0);
         if (c == c_last && lane < 32) {                  // the newest position joins the cache (read by later steps' launches)
             const u32x2 pk = *reinterpret_cast<const u32x2*>(kvg + (lane >> 4) * 64 + (lane & 15) * 4);
             bf16_t* plane = (lane >> 4) ? a.vcache : a.kcache;
@@ -182,7 +182,6 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
         }
     }
     __syncthreads();
-    if (tid == 0) xchg_note_slow(a.err, t_block);
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- (4) attention over chunk c (attn_decode.hpp, the launch chain's arithmetic; the newest position from the granules) ----------
