@@ -439,13 +439,16 @@ void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, ProIn in, cons
     hipError_t r = H16_CALL(e->hdt, HT, launch_rows_prologue<HT>(a, pro, rw.B, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_prologue launch failed: ") + hipGetErrorString(r));
 }
-void gemm_dec_ln(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
+// kind: the timeline's launch kind (StepTimer::trace_slot)
+void gemm_dec_ln(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kind) {
     if (!tm.on(0)) return;
+    a.trace = tm.trace_slot(kind, (a.N + 15) / 16);
     hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec_ln<HT>(a, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec_ln launch failed: ") + hipGetErrorString(r));
 }
-void gemm_dec(ma_engine* e, hipStream_t s, const GemmDecArgs& a, StepTimer& tm) {
+void gemm_dec(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kind) {
     if (!tm.on(0)) return;
+    a.trace = tm.trace_slot(kind, (a.N + 15) / 16 * std::max(1, a.ksplit));
     hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec<HT>(a, s));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec launch failed: ") + hipGetErrorString(r));
 }
@@ -496,8 +499,8 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             if (fold && l > 0) {
                 a.pin = qin.x; a.pin_stride = H; a.pin_parts = qin.nparts; a.pbias = qin.bias; a.pres = qin.res; a.pres_stride = H;
                 a.ln_g = e->dl[l - 1].ln2_g; a.ln_b = e->dl[l - 1].ln2_b; a.ln_eps = 1e-5f; a.xn_out = h0; a.xn_stride = H;
-                gemm_dec_ln(e, s, a, tm);
-            } else gemm_dec(e, s, a, tm);
+                gemm_dec_ln(e, s, a, tm, 1);
+            } else gemm_dec(e, s, a, tm, 1);
         }
         // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
         // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
@@ -524,7 +527,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.o_w); a.xb = xb; a.xb_stride = H; a.N = H; a.K = H; a.B = B; a.ksplit = ks_o_eff; a.y_stride = H;
             if (ks_o_eff > 1) a.y = partO; else { a.y = y1; a.bias = w.o_b; a.res = resid; a.res_stride = H; }
-            gemm_dec(e, s, a, tm);
+            gemm_dec(e, s, a, tm, 3);
         }
         ProIn in1;
         if (ks_o_eff > 1) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
@@ -536,14 +539,14 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             if (fold1) {
                 a.pin = in1.x; a.pin_stride = H; a.pin_parts = in1.nparts; a.pbias = in1.bias; a.pres = in1.res; a.pres_stride = H;
                 a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.xn_out = h1; a.xn_stride = H;
-                gemm_dec_ln(e, s, a, tm);
-            } else gemm_dec(e, s, a, tm);
+                gemm_dec_ln(e, s, a, tm, 4);
+            } else gemm_dec(e, s, a, tm, 4);
         }
         {   // y2 = h1 + W2 f + b2
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.fc2_w); a.xb = ffb; a.xb_stride = c.ffn; a.N = H; a.K = c.ffn; a.B = B; a.ksplit = ks_f; a.y_stride = H;
             if (ks_f > 1) a.y = partF; else { a.y = y2; a.bias = w.fc2_b; a.res = h1; a.res_stride = H; }
-            gemm_dec(e, s, a, tm);
+            gemm_dec(e, s, a, tm, 5);
         }
     }
     // lm_head on LN2_{L-1}(y2)
@@ -553,7 +556,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     GemmDecArgs g{};
     g.W = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); g.xb = xb; g.xb_stride = H;
     g.y = e->d_logits + r0 * e->V; g.y_stride = e->V; g.N = e->V; g.K = H; g.B = B; g.ksplit = 1;
-    gemm_dec(e, s, g, tm);
+    gemm_dec(e, s, g, tm, 6);
 }
 
 // The fused launches spin on granules written by other blocks of the same grid, so EVERY block of the grid (256 per batch row) must
@@ -699,7 +702,7 @@ void enqueue_layer_rows_fused(ma_engine* e, hipStream_t s, int l, const float* x
     }
 }
 
-bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
+bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && e->hdt == MA_DTYPE_BF16 && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
 
 // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp); belongs to the "cache" class of the profiler
 void enqueue_layer_pair(ma_engine* e, hipStream_t s, int l, const float* resid, int len_override, StepTimer& tm, Rows rw) {
@@ -1252,13 +1255,13 @@ void build_engine(ma_engine* e) {
             // the rows-looped launches: the second one holds 66-130 KB of LDS, i.e. ONE block per CU -- an LDS bound, where the occupancy
             // query is exact (its off-by-one concerns the SGPR-limited high-occupancy cases): 256 blocks need 256 CUs
             int occ_r = 0;
-            e->rf_ok = e->bf16 && rf_prepare() == hipSuccess &&
+            e->rf_ok = e->bf16 && e->hdt == MA_DTYPE_BF16 && rf_prepare() == hipSuccess &&
                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_r, oproj_fc1_rows_kernel<8>, 256, rf_oproj_lds(8)) == hipSuccess && (long)e->n_cus * occ_r >= 256;
             if (!e->rf_ok) (void)hipGetLastError();
 #endif
         }
 #ifdef MA_EXPERIMENTAL
-        e->persist_shape = e->bf16 && c.hidden == PS_H && c.ffn == PS_F && c.heads == PS_HEADS && c.codebook_dim == PS_H && c.heads * ATTN_NCHUNK == PS_CUS &&
+        e->persist_shape = e->bf16 && e->hdt == MA_DTYPE_BF16 && c.hidden == PS_H && c.ffn == PS_F && c.heads == PS_HEADS && c.codebook_dim == PS_H && c.heads * ATTN_NCHUNK == PS_CUS &&
                            e->V >= PS_CUS * 32 && e->V <= PS_CUS * 33 && e->n_cus == PS_CUS && (size_t)prop.sharedMemPerBlockOptin >= PL_TOTAL;
         if (e->persist_shape && persist_prepare() != hipSuccess) { (void)hipGetLastError(); e->persist_shape = false; }
         if (e->persist_shape) {

@@ -42,7 +42,87 @@ struct GemmDecArgs {
     const float* pin; int pin_stride; int pin_parts; const float* pbias; const float* pres; int pres_stride;
     const float* ln_g; const float* ln_b; float ln_eps;
     float* xn_out; int xn_stride;        // LN output fp32 (a later residual), written by block (0, 0); may be null
+    unsigned long long* trace;           // diagnostics (ma_trace_decode): 4 stamps of the 100 MHz counter per block, or null
 };
+__device__ __forceinline__ void gd_stamp(const GemmDecArgs& a, int i) {
+    if (a.trace && threadIdx.x == 0) a.trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + i] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---- epilogue of one lane: four consecutive outputs n = r0 .. r0 + 3 of batch row b ------------------------------------------------
+// Its operands (bias, residual, the row's write position) are REQUESTED before the weight stream and only consumed here: read where
+// they are used, each was a dependent L2 round trip of its own behind the matrix product (8 of them in a q/k/v epilogue: 1.5 us of a
+// 4 us launch, profiles/r04_decode_step_timeline_b8.txt).  `vec`: the four outputs are inside N and every row stride is a multiple of
+// four elements -- one 16-byte access per operand; otherwise element by element (the odd-sized lm_head).
+struct GdEpi { f32x4 bias, res; int pos; };
+__device__ __forceinline__ bool gd_vec(const GemmDecArgs& a, int n0) {
+    return n0 + 16 <= a.N && ((a.res_stride | a.y_stride | a.yb_stride) & 3) == 0;
+}
+__device__ __forceinline__ GdEpi gd_epi_request(const GemmDecArgs& a, int b, int r0) {
+    // element by element with clamped indices, under block-uniform conditions only: a lane-dependent branch around a request (or two
+    // request forms merging into one variable) makes hipcc wait for the data where the branch ends -- in front of the weight stream
+    GdEpi e; e.bias = f32x4{0.f, 0.f, 0.f, 0.f}; e.res = e.bias; e.pos = 0;
+    if (a.ksplit > 1) return e;
+    if (a.epi == EPI_QKV) e.pos = a.st[b].pos;
+    const int n1 = a.N - 1;
+    if (a.bias) e.bias = f32x4{a.bias[min(r0, n1)], a.bias[min(r0 + 1, n1)], a.bias[min(r0 + 2, n1)], a.bias[min(r0 + 3, n1)]};
+    if (a.res) {
+        const float* rp = a.res + (size_t)b * a.res_stride;
+        e.res = f32x4{rp[min(r0, n1)], rp[min(r0 + 1, n1)], rp[min(r0 + 2, n1)], rp[min(r0 + 3, n1)]};
+    }
+    return e;
+}
+template <typename HT>
+__device__ __forceinline__ void gd_epi_store(const GemmDecArgs& a, const GdEpi& e, const f32x4& v, int b, int r0, bool vec) {
+    if (a.ksplit > 1) {                                   // raw partial sums; bias / residual / norm happen in the consumer's prologue
+        float* yp = a.y + ((size_t)blockIdx.y * a.B + b) * a.y_stride + r0;
+        if (vec) *reinterpret_cast<f32x4*>(yp) = v;
+        else {
+            const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (r0 + r < a.N) yp[r] = o[r];
+        }
+        return;
+    }
+    float x[4] = {v.x, v.y, v.z, v.w};
+    const float bb[4] = {e.bias.x, e.bias.y, e.bias.z, e.bias.w}, rr[4] = {e.res.x, e.res.y, e.res.z, e.res.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (a.bias) x[r] += bb[r];
+        x[r] = apply_act(x[r], a.act);
+        if (a.res) x[r] += rr[r];
+    }
+    if (a.epi == EPI_QKV) {                               // r0 is a multiple of 4 and H of 64: the four outputs share their part and head
+        const int part = r0 / a.H, c = r0 - part * a.H;
+        if (part == 0) {
+            float* q = a.y + (size_t)b * a.y_stride + c;
+            if (vec) *reinterpret_cast<f32x4*>(q) = f32x4{x[0], x[1], x[2], x[3]};
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r0 + r < a.N) q[r] = x[r];
+            }
+        } else {
+            const int head = c >> 6, d = c & 63;
+            const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + e.pos) * 64 + d;
+            bf16_t* dst = reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache) + off;
+            if (vec) *reinterpret_cast<u32x2*>(dst) = pack4<HT>(f32x4{x[0], x[1], x[2], x[3]});
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r0 + r < a.N) dst[r] = H16<HT>::bits(x[r]);
+            }
+        }
+        return;
+    }
+    if (vec) {
+        if (a.y) *reinterpret_cast<f32x4*>(a.y + (size_t)b * a.y_stride + r0) = f32x4{x[0], x[1], x[2], x[3]};
+        if (a.yb) *reinterpret_cast<u32x2*>(a.yb + (size_t)b * a.yb_stride + r0) = pack4<HT>(f32x4{x[0], x[1], x[2], x[3]});
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r0 + r < a.N) {
+            if (a.y) a.y[(size_t)b * a.y_stride + r0 + r] = x[r];
+            if (a.yb) a.yb[(size_t)b * a.yb_stride + r0 + r] = H16<HT>::bits(x[r]);
+        }
+    }
+}
 
 // HT (all kernels of this file): the 16-bit format of weights, activations and cache (bf16_t | f16_t, common.hpp H16)
 template <int MT, int CH, typename HT = bf16_t>
@@ -51,12 +131,18 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    gd_stamp(a, 0); gd_stamp(a, 1);
     const int K = a.K, Kw = K / (4 * a.ksplit);            // k-range of one wave
     const int kbase = (blockIdx.y * 4 + w) * Kw + kg * 8;
     const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + kbase;
     const bf16_t* xrow[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) xrow[t] = a.xb + (size_t)min(t * 16 + m, a.B - 1) * a.xb_stride + kbase;
+    // wave t finishes batch tile t (MT <= 4): its epilogue operands go out in front of the weight stream
+    const int eb = w * 16 + m, r0 = n0 + kg * 4;           // batch row / first of the four consecutive outputs of this lane
+    const bool e_on = w < MT && eb < a.B, vec = gd_vec(a, n0);
+    const GdEpi ep = gd_epi_request(a, min(eb, a.B - 1), r0);      // every lane asks (clamped row): a lane-dependent branch around the
+                                                                         // requests would make hipcc wait for them at its end
 
     f32x4 acc[MT];
 #pragma unroll
@@ -80,56 +166,31 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) *reinterpret_cast<f32x4*>(&red[w][t][lane][0]) = acc[t];
     __syncthreads();
-    // epilogue: wave t finishes batch tile t (MT <= 4)
-    if (w >= MT) return;
-    const int t = w;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][t][lane][0]);
+    gd_stamp(a, 2);
+    if (!e_on) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][w][lane][0]);
 #pragma unroll
     for (int i = 1; i < 4; ++i) {
-        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][t][lane][0]);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][w][lane][0]);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    const int b = t * 16 + m;                             // batch row of this lane
-    if (b >= a.B) return;
-    const int r0 = n0 + kg * 4;                           // first of this lane's four consecutive output rows
-    float o[4] = {v.x, v.y, v.z, v.w};
-    if (a.ksplit > 1) {                                   // raw partial sums; bias / residual / norm happen in the consumer's prologue
-        float* yp = a.y + ((size_t)blockIdx.y * a.B + b) * a.y_stride;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r0 + r < a.N) yp[r0 + r] = o[r];
-        return;
-    }
-    const int pos = a.epi == EPI_QKV ? a.st[b].pos : 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = r0 + r;
-        if (n >= a.N) continue;
-        float x = o[r];
-        if (a.bias) x += a.bias[n];
-        x = apply_act(x, a.act);
-        if (a.res) x += a.res[(size_t)b * a.res_stride + n];
-        if (a.epi == EPI_QKV) {
-            const int part = n / a.H, c = n - part * a.H;
-            if (part == 0) a.y[(size_t)b * a.y_stride + c] = x;
-            else {
-                const int head = c >> 6, d = c & 63;
-                const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
-                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = H16<HT>::bits(x);
-            }
-        } else {
-            if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
-            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = H16<HT>::bits(x);
-        }
-    }
+    gd_epi_store<HT>(a, ep, v, eb, r0, vec);
+    gd_stamp(a, 3);
 }
 
 // Small batches (B <= 16: one MFMA batch tile): the per-row LayerNorm prologue runs INSIDE the consuming GEMM instead of in a launch
 // of its own (a decode step of 4-16 rows is launch-latency bound: 5 us per dependent launch).  Every block normalises all B rows itself
-// -- one wave per row, rows w, w + 4, ...: sum of the producer's partial buffers in their fixed order + bias + residual, one-pass
+// -- one wave per row, rows w, w + 4, ...: sum of the producer's PARTS partial buffers in their fixed order + bias + residual, one-pass
 // shifted statistics (common.hpp), wave-level reduction -- and parks them in LDS as bf16 (row stride padded by 32 bytes: the 16 rows
-// of an MFMA B fragment land in different banks).  The weight rows of the block (its whole K range: 8 loads per lane) are requested
-// before the prologue.  Same MFMA mapping and epilogues as gemm_dec_kernel.  K = 1024 (the hidden size).
-template <typename HT = bf16_t>
+// of an MFMA B fragment land in different banks).  Same MFMA mapping and epilogues as gemm_dec_kernel.  K = 1024 (the hidden size).
+// Everything the prologue reads is requested in as few dependent steps as the registers allow: the block's weight rows (whole K range:
+// 8 loads per lane), LayerNorm parameters, deferred bias and the epilogue's operands first; then ALL vectors of a row together (PARTS
+// partials + residual), two rows at a time when PARTS <= 2.  Summing partial by partial, row by row, parameters by chunk -- the first
+// form of this kernel -- was ~20 dependent L2 round trips: 6.8 us of prologue in front of q/k/v, 4.6 us in front of fc1, against 2.3 us
+// for the whole weight stream of a launch without prologue (profiles/r04_decode_step_timeline_b8.txt).
+// DEFER: the producer's deferred epilogue (bias `pbias` + residual `pres`, both or neither) is added in front of the LayerNorm -- a
+// template flag, not a branch: requests inside a branch make hipcc wait for them where the branch ends
+template <int PARTS, bool DEFER, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     constexpr int K = 1024, CH = 8, XS = K + 16;             // XS: LDS row stride in bf16 elements (32 bytes of padding: conflict-free fragments)
     __shared__ __attribute__((aligned(16))) float red[4][64][4];
@@ -137,64 +198,91 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    gd_stamp(a, 0);
     const int kbase = w * 256 + kg * 8;
     const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + kbase;
-    u32x4 wv[CH];
+    // parameters every row shares, and the epilogue's operands (wave 0 finishes the block; lane: batch row m, outputs n0 + 4 kg ..)
+    f32x4 gv[4], bv[4], pb[4];
 #pragma unroll
-    for (int s = 0; s < CH; ++s) wv[s] = ld_stream16(wrow + s * 32);
+    for (int j = 0; j < 4; ++j) {
+        const int idx = (lane + 64 * j) * 4;
+        gv[j] = *reinterpret_cast<const f32x4*>(a.ln_g + idx);
+        bv[j] = *reinterpret_cast<const f32x4*>(a.ln_b + idx);
+        if constexpr (DEFER) pb[j] = *reinterpret_cast<const f32x4*>(a.pbias + idx);
+    }
+    const int r0 = n0 + kg * 4;
+    const bool e_on = w == 0 && m < a.B;
+    const bool vec = gd_vec(a, n0);
+    const GdEpi ep = gd_epi_request(a, min(m, a.B - 1), r0);       // (every lane asks, clamped row: no lane-dependent branch around the requests)
     asm volatile("" ::: "memory");
 
-    // ---- prologue: rows w, w + 4, ...; two rows per pass so that the second row's loads fly under the first row's arithmetic -------------
+    // ---- prologue: rows w, w + 4, ... ------------------------------------------------------------------------------------------------
     const bool writer = blockIdx.x == 0 && a.xn_out;
-    auto load_row = [&](int r, f32x4 (&xv)[4], float& x0) {          // sum of the partial buffers in their order, + bias, + residual
+    auto request_row = [&](int r, f32x4 (&xv)[PARTS][4], f32x4 (&rv)[4]) {
         const float* x = a.pin + (size_t)r * a.pin_stride;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const f32x4*>(x + (lane + 64 * j) * 4);
-        x0 = x[0];
-        for (int p = 1; p < a.pin_parts; ++p) {
-            const float* xp = x + (size_t)p * a.B * a.pin_stride;
+        for (int p = 0; p < PARTS; ++p)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(xp + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
-            x0 += xp[0];
+            for (int j = 0; j < 4; ++j) xv[p][j] = *reinterpret_cast<const f32x4*>(x + (size_t)p * a.B * a.pin_stride + (lane + 64 * j) * 4);
+        if constexpr (DEFER) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const f32x4*>(a.pres + (size_t)r * a.pres_stride + (lane + 64 * j) * 4);
         }
-        if (a.pbias) {
+        asm volatile("" ::: "memory");
+    };
+    auto sum_row = [&](f32x4 (&xv)[PARTS][4], f32x4 (&rv)[4], f32x4 (&s)[4]) {      // the partial buffers in their order, + bias, + residual
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.pbias + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
-            x0 += a.pbias[0];
-        }
-        if (a.pres) {
-            const float* rp = a.pres + (size_t)r * a.pres_stride;
+        for (int j = 0; j < 4; ++j) {
+            s[j] = xv[0][j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp + (lane + 64 * j) * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
-            x0 += rp[0];
+            for (int p = 1; p < PARTS; ++p) { s[j].x += xv[p][j].x; s[j].y += xv[p][j].y; s[j].z += xv[p][j].z; s[j].w += xv[p][j].w; }
+            if constexpr (DEFER) {
+                s[j].x += pb[j].x; s[j].y += pb[j].y; s[j].z += pb[j].z; s[j].w += pb[j].w;
+                s[j].x += rv[j].x; s[j].y += rv[j].y; s[j].z += rv[j].z; s[j].w += rv[j].w;
+            }
         }
     };
-    auto finish_row = [&](int r, f32x4 (&xv)[4], float x0) {
+    auto norm_row = [&](int r, f32x4 (&s)[4]) {
+        const float x0 = readlane_f(s[0].x, 0);            // element 0 of the summed row: the statistics' shift (lane 0 holds it)
         float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ln_chunk_moments(xv[j], x0, sm, sq);
+        for (int j = 0; j < 4; ++j) ln_chunk_moments(s[j], x0, sm, sq);
         sm = wave_sum(sm); sq = wave_sum(sq);
         float md, rstd;
         ln_finish(sm, 0.f, 0.f, 0.f, sq, 0.f, 0.f, 0.f, K, a.ln_eps, md, rstd);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = (lane + 64 * j) * 4;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + idx), bb = *reinterpret_cast<const f32x4*>(a.ln_b + idx);
-            ln_apply(xv[j], md, rstd, g, bb);
-            if (writer) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)r * a.xn_stride + idx) = xv[j];
-            *reinterpret_cast<u32x2*>(&xl[r * XS + idx]) = pack4<HT>(xv[j]);
+            ln_apply(s[j], md, rstd, gv[j], bv[j]);
+            if (writer) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)r * a.xn_stride + idx) = s[j];
+            *reinterpret_cast<u32x2*>(&xl[r * XS + idx]) = pack4<HT>(s[j]);
         }
     };
-    for (int r = w; r < a.B; r += 8) {
-        f32x4 xa[4], xb2[4];
-        float x0a, x0b = 0.f;
-        const bool two = r + 4 < a.B;
-        load_row(r, xa, x0a);
-        if (two) load_row(r + 4, xb2, x0b);
-        finish_row(r, xa, x0a);
-        if (two) finish_row(r + 4, xb2, x0b);
+    // Loads come back in the order they were asked for (one counter), so the activation rows -- L2 hits -- are asked for BEFORE the block's
+    // weight rows -- an HBM stream: the LayerNorm arithmetic then runs while the weights are on their way.
+    u32x4 wv[CH];
+    {
+        const int ra_ = w, rb_ = w + 4;                    // rows of the first pass (B <= 8: the only one)
+        const bool one = ra_ < a.B, two = rb_ < a.B;
+        f32x4 xa[PARTS][4], xb2[PARTS][4], va[4], vb[4], sa[4], sb[4];
+        if (one) request_row(ra_, xa, va);
+        if constexpr (PARTS > 2) { if (one) sum_row(xa, va, sa); }     // 4 partials + residual = 80 registers: the first row collapses before
+        if (two) request_row(rb_, xb2, vb);                              // the second is asked for
+#pragma unroll
+        for (int s = 0; s < CH; ++s) wv[s] = ld_stream16(wrow + s * 32);
+        asm volatile("" ::: "memory");
+        if constexpr (PARTS <= 2) { if (one) sum_row(xa, va, sa); }
+        if (one) norm_row(ra_, sa);
+        if (two) { sum_row(xb2, vb, sb); norm_row(rb_, sb); }
+    }
+    for (int r = w + 8; r < a.B; r += 4) {                 // 9 .. 16 rows: one row at a time
+        f32x4 xa[PARTS][4], va[4], sa[4];
+        request_row(r, xa, va);
+        sum_row(xa, va, sa);
+        norm_row(r, sa);
     }
     __syncthreads();
+    gd_stamp(a, 1);
 
     // ---- MFMA: A = the block's 16 weight rows, B = the 16 (<= B valid) activation rows from LDS ---------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -206,46 +294,30 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     }
     *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
     __syncthreads();
-    if (w != 0) return;
+    gd_stamp(a, 2);
+    if (!e_on) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
 #pragma unroll
     for (int i = 1; i < 4; ++i) {
         const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][lane][0]);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    const int b = m;
-    if (b >= a.B) return;
-    const int r0 = n0 + kg * 4;
-    float o[4] = {v.x, v.y, v.z, v.w};
-    const int pos = a.epi == EPI_QKV ? a.st[b].pos : 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = r0 + r;
-        if (n >= a.N) continue;
-        float x = o[r];
-        if (a.bias) x += a.bias[n];
-        x = apply_act(x, a.act);
-        if (a.res) x += a.res[(size_t)b * a.res_stride + n];
-        if (a.epi == EPI_QKV) {
-            const int part = n / a.H, c = n - part * a.H;
-            if (part == 0) a.y[(size_t)b * a.y_stride + c] = x;
-            else {
-                const int head = c >> 6, d = c & 63;
-                const size_t off = (size_t)b * a.kv_row_stride + ((size_t)head * a.max_seq + pos) * 64 + d;
-                reinterpret_cast<bf16_t*>(part == 1 ? a.kcache : a.vcache)[off] = H16<HT>::bits(x);
-            }
-        } else {
-            if (a.y) a.y[(size_t)b * a.y_stride + n] = x;
-            if (a.yb) a.yb[(size_t)b * a.yb_stride + n] = H16<HT>::bits(x);
-        }
-    }
+    gd_epi_store<HT>(a, ep, v, m, r0, vec);
+    gd_stamp(a, 3);
 }
 
 template <typename HT>
 inline hipError_t launch_gemm_dec_ln(const GemmDecArgs& a, hipStream_t s) {
-    if (a.K != 1024 || a.B < 1 || a.B > 16 || a.ksplit != 1 || !a.pin || a.pin_parts < 1 || !a.ln_g || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) ||
+    if (a.K != 1024 || a.B < 1 || a.B > 16 || a.ksplit != 1 || !a.pin || !a.ln_g || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) ||
         (a.xn_out && a.xn_stride % 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_dec_ln_kernel<HT>), dim3((a.N + 15) / 16), dim3(256), 0, s, a);
+    if ((a.pbias != nullptr) != (a.pres != nullptr)) return hipErrorInvalidValue;          // the deferred epilogue comes whole
+    const dim3 grid((a.N + 15) / 16), block(256);
+    const bool d = a.pres != nullptr;
+    if (a.pin_parts == 1 && !d) hipLaunchKernelGGL((gemm_dec_ln_kernel<1, false, HT>), grid, block, 0, s, a);
+    else if (a.pin_parts == 1) hipLaunchKernelGGL((gemm_dec_ln_kernel<1, true, HT>), grid, block, 0, s, a);
+    else if (a.pin_parts == 2 && d) hipLaunchKernelGGL((gemm_dec_ln_kernel<2, true, HT>), grid, block, 0, s, a);
+    else if (a.pin_parts == 4 && d) hipLaunchKernelGGL((gemm_dec_ln_kernel<4, true, HT>), grid, block, 0, s, a);
+    else return hipErrorInvalidValue;                  // (gemm_dec_ksplit gives 1, 2 or 4)
     return hipGetLastError();
 }
 

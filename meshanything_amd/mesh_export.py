@@ -1,20 +1,33 @@
 """Output side of the hot path: (n_max_triangles, 3, 3) coordinates -> a triangle mesh file (main.py:156-175).
 
-The reference hands the vertices to trimesh (`Trimesh(..., merge_primitives=True)`, `merge_vertices()`,
-`update_faces(unique_faces())`, `fix_normals()`, `export(.obj)`).  trimesh is not part of this image; the steps that
-change the *content* of the file are restated here on exact coordinates (the detokenizer emits multiples of 1/128, so
-"same vertex" is exact equality -- no tolerance needed):
-  drop NaN faces -> merge identical vertices -> drop faces that repeat an earlier face's vertex SET (trimesh's
-  unique_faces sorts each face's indices) -> write OBJ.
-`fix_normals()` = trimesh.repair.fix_winding + fix_inversion: faces that share an edge are given consistent winding by a
-breadth-first traversal of the face-adjacency graph (edges shared by exactly two faces); then -- `Trimesh.fix_normals`
-resolves `multibody=None` to `body_count > 1`, and MeshAnything outputs usually have several bodies -- every connected
-body whose own signed volume is negative is flipped (one body: the whole mesh by its total volume, which is the same
-thing).  Faces that share no manifold edge with any other face are not part of any body in trimesh's
-`connected_components(face_adjacency)` and keep their winding.  `fix_normals` below restates that; where a body is not
-orientable (or an edge has more than two faces) the result depends on the traversal order, here lowest face index first --
-trimesh's order comes from networkx and is not reproduced bit for bit.  (trimesh is not installed in this image: the
-restatement follows its published algorithm and cannot be pinned against it here.)
+The reference hands the vertices to trimesh (requirements.txt pins trimesh==4.2.3): `Trimesh(vertices, faces)` (process=True:
+`merge_vertices()` once at construction), `merge_vertices()`, `update_faces(unique_faces())`, `fix_normals()`,
+`visual.face_colors = (255, 165, 0, 255)`, `export(.obj)`.  trimesh is not part of this image, so nothing here can be run
+against it; the steps below restate what trimesh 4.2.3 publishes for each call, and tests/test_mesh_export.py holds
+hand-derived expectations (file text included) for them:
+
+  merge_vertices   grouping.merge_vertices: rows of round(vertices * 1e8) (tol.merge = 1e-8) that are equal become one vertex;
+                   `unique_rows(..., keep_order=True)` keeps the merged vertices in the order of their FIRST OCCURRENCE.  The
+                   detokenizer emits multiples of 1/128 in [-0.5, 0.5], which differ by >= 7.8e-3 or not at all, so "equal after
+                   rounding to 8 decimals" is exact equality of the float32 values here.
+  unique_faces     rows of np.sort(faces, axis=1): the first face of every vertex SET stays, in the original face order.
+                   Degenerate faces (a repeated vertex) stay: the constructor runs process(validate=False).
+  fix_normals      repair.fix_winding + repair.fix_inversion, `multibody=None` resolved to `body_count > 1` where body_count
+                   counts the connected components of the VERTEX graph (every edge of every face):
+                   * fix_winding: breadth-first over the face-adjacency graph (pairs of faces sharing an edge that exactly two
+                     faces use; a face is never adjacent to itself); the second face of a traversed pair is reversed ([::-1]) when
+                     both run along the shared edge in the same direction.
+                   * fix_inversion, multibody: groups = connected components of the face-adjacency graph (faces with no manifold
+                     edge belong to no group); exactly one group -> the WHOLE mesh is reversed when its total signed volume is
+                     negative; several -> every group whose own signed volume is negative is reversed (np.fliplr).
+                   * fix_inversion, one body: the whole mesh is reversed when its total signed volume is negative.
+                   For an orientable body the result does not depend on where the traversal starts (consistent winding is unique
+                   up to a flip of the body, and the volume sign settles the flip).  Where a body is NOT orientable the result
+                   depends on the traversal order -- lowest face index first here, networkx's node order in trimesh: not
+                   reproduced, and said so.
+  export(.obj)     exchange/obj.export_obj: a `# <header>` line, `v x y z r g b` lines ('{:.8f}'; face colours become vertex colours,
+                   one colour on every face gives every vertex that colour, written as uint8 / 255), `f a b c` lines (1-based), no
+                   normals (none cached), no texture.  The header comment is this package's, not trimesh's URL.
 """
 from __future__ import annotations
 
@@ -30,16 +43,38 @@ def faces_from_coords(coords: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     tri = coords[valid].reshape(-1, 3)                          # 3 * n_valid vertices, face i = rows 3i..3i+2
     if tri.shape[0] == 0:
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64)
-    verts, inverse = np.unique(tri, axis=0, return_inverse=True)            # merge_vertices on exact coordinates
-    faces = inverse.reshape(-1, 3).astype(np.int64)
+    # merge_vertices on exact coordinates, merged vertices in first-occurrence order (unique_rows(..., keep_order=True))
+    verts, first_v, inverse = np.unique(tri, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first_v, kind="stable")
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    verts = verts[order]
+    faces = rank[np.asarray(inverse).reshape(-1)].reshape(-1, 3).astype(np.int64)
     key = np.sort(faces, axis=1)
     _, first = np.unique(key, axis=0, return_index=True)                     # unique_faces: first occurrence of each vertex set
     faces = faces[np.sort(first)]
     return verts.astype(np.float32), faces
 
 
+def _vertex_body_count(n_verts: int, faces: np.ndarray) -> int:
+    """Trimesh.body_count: connected components of the vertex graph whose edges are the edges of every face (union-find)."""
+    parent = np.arange(n_verts)
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b, c in faces:
+        ra, rb, rc = find(a), find(b), find(c)
+        parent[rb] = ra
+        parent[find(rc)] = ra
+    return len({find(v) for v in range(n_verts)})
+
+
 def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
-    """Consistent winding across shared edges, then outward orientation (positive signed volume) per connected body.
+    """Trimesh.fix_normals() of trimesh 4.2.3 (module docstring): consistent winding across manifold edges, then outward
+    orientation by signed volume -- per face-adjacency group when the vertex graph has several components, else as a whole.
     Returns new faces."""
     faces = np.array(faces, dtype=np.int64, copy=True)
     n = len(faces)
@@ -53,7 +88,7 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
             edge_faces.setdefault((min(u, v), max(u, v)), []).append(f)
     adj = [[] for _ in range(n)]
     for (u, v), fs in edge_faces.items():
-        if len(fs) == 2:                                     # manifold edges only, as trimesh.face_adjacency
+        if len(fs) == 2 and fs[0] != fs[1]:                  # manifold edges only, never a face with itself (graph.face_adjacency)
             adj[fs[0]].append((fs[1], u, v))
             adj[fs[1]].append((fs[0], u, v))
 
@@ -62,14 +97,14 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
         return (a == u and b == v) or (b == u and c == v) or (c == u and a == v)
 
     seen = np.zeros(n, dtype=bool)
-    bodies = []
+    groups = []                                              # face-adjacency components: faces with at least one manifold edge
     for root in range(n):
-        if seen[root]:
+        if seen[root] or not adj[root]:
             continue
         seen[root] = True
         queue = [root]
         body = [root]
-        bodies.append(body)
+        groups.append(body)
         while queue:
             f = queue.pop(0)
             for g, u, v in sorted(adj[f]):
@@ -81,11 +116,15 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
                 seen[g] = True
                 queue.append(g)
                 body.append(g)
-    tri = verts[faces].astype(np.float64)
+    tri = np.asarray(verts)[faces].astype(np.float64)
     signed6 = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2]))      # 6 x signed tetrahedron volume per face
-    for body in bodies:
-        if len(body) > 1 and signed6[body].sum() < 0:
-            faces[body] = faces[body][:, ::-1]
+    multibody = _vertex_body_count(len(verts), faces) > 1
+    if multibody and len(groups) != 1:
+        for body in groups:                                  # (no group at all: nothing to orient)
+            if signed6[body].sum() < 0:
+                faces[body] = faces[body][:, ::-1]
+    elif signed6.sum() < 0:                                  # one body, or one group: Trimesh.invert() of the whole mesh
+        faces = faces[:, ::-1].copy()
     return faces
 
 

@@ -44,9 +44,16 @@ for k, cs in den.items():
         continue
     rows[k] = {"dispatches": mf["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": round(mf["mean"], 1), "GRBM_GUI_ACTIVE": round(ga["mean"], 1),
                "mfma_busy_frac": round(mf["mean"] / (ga["mean"] / 8.0 * 1024), 4)}
-tot_m = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["dispatches"] for v in rows.values())
-tot_all = sum(cs["GRBM_GUI_ACTIVE"]["mean"] * cs["GRBM_GUI_ACTIVE"]["dispatches"] for k, cs in den.items() if "GRBM_GUI_ACTIVE" in cs and any(t in k for t in ("gemm_tile", "attention_mfma", "vt_pack", "ln_rows2", "kv_fill2", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")))
+DENSE = ("gemm_tile", "gemm256", "gemm_dec", "gemm_mfma_f32", "attention", "vt_pack", "ln_rows2", "kv_fill2", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")
+def is_f32(k):                       # kernels of the exact (fp32) point encoder: fp32 matrix path, fp32 attention, fp32 row kernels
+    return "gemm_mfma_f32" in k or "attention_f32" in k or ("<float>" in k and "unsigned short" not in k and "_Float16" not in k)
+def busy(pred):
+    m = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["dispatches"] for k, v in rows.items() if pred(k))
+    a = sum(cs["GRBM_GUI_ACTIVE"]["mean"] * cs["GRBM_GUI_ACTIVE"]["dispatches"] for k, cs in den.items()
+            if "GRBM_GUI_ACTIVE" in cs and any(t in k for t in DENSE) and pred(k))
+    return round(m / max(1.0, a / 8.0 * 1024), 4)
 json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace on scripts/prof_dense.py --batches 64 --iters 1",
-           "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); dense_phase = MFMA cycles of all kernels / active cycles of all dense-phase kernels (GEMM, attention, LayerNorm, gathers)",
-           "dense_phase_mfma_busy_frac": round(tot_m / max(1.0, tot_all / 8.0 * 1024), 4), "per_kernel": rows},
+           "formula": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); a phase = MFMA cycles of its kernels / active cycles of ALL its kernels (GEMM, attention, LayerNorm, gathers, casts)",
+           "dense_16bit_phases_mfma_busy_frac": busy(lambda k: not is_f32(k)), "fp32_encoder_mfma_busy_frac": busy(is_f32),
+           "dense_phase_mfma_busy_frac": busy(lambda k: True), "per_kernel": rows},
           open(os.path.join(out, RND + "_pmc_dense_mfma.json"), "w"), indent=1, sort_keys=True)

@@ -70,3 +70,71 @@ def test_fix_normals_orients_every_body_on_its_own():
     fixed = fix_normals(v, faces)
     assert abs(_signed_volume(v, fixed[:4]) - 1 / 6) < 1e-9 and np.array_equal(fixed[:4], good)
     assert _signed_volume(v, fixed[4:]) > 0
+
+
+# ---- hand-derived expectations from trimesh 4.2.3's published behaviour (mesh_export.py docstring; trimesh itself is not installed here) ----
+def _square(z):
+    c = np.full((4, 3, 3), np.nan, dtype=np.float32)
+    c[0] = [[0, 0, z], [0.5, 0, z], [0, 0.5, z]]             # counter-clockwise seen from +z
+    c[2] = [[0.5, 0, z], [0, 0.5, z], [0.5, 0.5, z]]         # clockwise: runs along the shared edge the same way as face 0
+    c[3] = [[0, 0.5, z], [0, 0, z], [0.5, 0, z]]             # the vertex set of face 0 again: unique_faces drops it
+    return c
+
+
+COL = " 1.00000000 0.64705882 0.00000000"
+
+
+def test_obj_text_of_a_hand_derived_case(tmp_path):
+    """Vertices in first-occurrence order; face 2 reversed by fix_winding ([::-1] of (2, 3, 4) = (4, 3, 2), 1-based); the open
+    surface at z = +1/4 has 6 V = 0.0625 + 0.0625 > 0 and stays, the same surface at z = -1/4 has 6 V < 0 and is reversed
+    as a whole (np.fliplr of every face)."""
+    for z, faces_txt in ((0.25, ["f 1 2 3", "f 4 3 2"]), (-0.25, ["f 3 2 1", "f 2 3 4"])):
+        v, f = faces_from_coords(_square(z))
+        f = fix_normals(v, f)
+        p = tmp_path / "sq.obj"
+        write_obj(str(p), v, f)
+        zt = f"{z:.8f}"
+        want = ["# MeshAnything (meshanything_amd)",
+                f"v 0.00000000 0.00000000 {zt}{COL}", f"v 0.50000000 0.00000000 {zt}{COL}",
+                f"v 0.00000000 0.50000000 {zt}{COL}", f"v 0.50000000 0.50000000 {zt}{COL}"] + faces_txt
+        assert p.read_text().splitlines() == want
+
+
+def test_vertices_keep_first_occurrence_order_not_sorted_order():
+    c = np.array([[[0.5, 0.5, 0.5], [-0.5, 0, 0], [0, 0.25, 0]], [[0, 0.25, 0], [-0.5, 0, 0], [0.25, -0.5, 0.125]]], np.float32)
+    v, f = faces_from_coords(c)
+    assert np.array_equal(v, np.array([[0.5, 0.5, 0.5], [-0.5, 0, 0], [0, 0.25, 0], [0.25, -0.5, 0.125]], np.float32))
+    assert np.array_equal(f, [[0, 1, 2], [2, 1, 3]])
+
+
+def test_degenerate_faces_stay_and_never_pair_with_themselves():
+    c = np.array([[[0, 0, 0], [0, 0, 0], [0.5, 0, 0]], [[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0]]], np.float32)   # face 0 repeats a vertex
+    v, f = faces_from_coords(c)
+    assert f.tolist() == [[0, 0, 1], [0, 1, 2]]              # process(validate=False): not removed
+    assert fix_normals(v, f).tolist() == [[0, 0, 1], [0, 1, 2]]   # edge (0, 1) is used three times: not manifold, nothing to traverse
+
+
+def test_one_group_plus_a_loose_face_is_oriented_as_a_whole():
+    """Vertex graph with two components (body_count 2 -> multibody) but ONE face-adjacency group: fix_inversion's single-group
+    escape reverses the whole mesh by its total volume -- the loose triangle included."""
+    v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    good = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
+    v = np.concatenate([v1, np.array([[5, 5, 5], [6, 5, 5], [5, 6, 5]], np.float32)])
+    loose = np.array([[4, 5, 6]])                            # 6 V = v0 . (v1 x v2) = +5
+    fixed = fix_normals(v, np.concatenate([good[:, ::-1], loose]))          # total 6 V = -1 + 5 > 0: nothing reversed, the body stays inverted
+    assert np.array_equal(fixed, np.concatenate([good[:, ::-1], loose]))
+    loose_neg = loose[:, ::-1]                               # 6 V = -5: total -6 < 0 -> every face reversed
+    fixed = fix_normals(v, np.concatenate([good[:, ::-1], loose_neg]))
+    assert np.array_equal(fixed, np.concatenate([good, loose]))
+
+
+def test_bodies_that_touch_in_one_vertex_count_as_one_body():
+    """Two tetrahedra sharing a single vertex: body_count == 1 (the vertex graph is connected), so multibody is False and the mesh is
+    reversed as a whole by its TOTAL volume, although face adjacency sees two groups."""
+    v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    good = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
+    v = np.concatenate([v1, -3 * v1[1:]])                    # second tetrahedron (0, 4, 5, 6): mirrored through the shared origin, 27 x the volume
+    big = np.array([[0, 5, 4], [0, 4, 6], [4, 5, 6], [0, 6, 5]])            # the mirror image of `good`'s pattern: inward (V = -27/6)
+    assert _signed_volume(v, big) < 0 < _signed_volume(v, good)
+    fixed = fix_normals(v, np.concatenate([good, big]))
+    assert np.array_equal(fixed, np.concatenate([good, big])[:, ::-1])      # total < 0: both reversed, the small one now inward
