@@ -296,8 +296,8 @@ inline hipError_t launch_attn_decode(const float* q, const void* kc, const void*
 // q_len 1, one call per layer).  NW = 4 from 12 rows on (>= 192 blocks); 8 <= rows < 12 give 128-176 blocks, which stream
 // with NW = 8 waves each; below 8 rows the split form wins (too few blocks).  Same per-slot arithmetic
 // (attn_round_reduce) as the split form; only the grouping of positions into partial states differs.
-// SPLIT2 (8..11 rows: 128-176 (row, head) pairs leave half of the CUs without a block): TWO blocks per pair, each over half of the
-// rounds; block z = 0 hands its (m, l, o[64]) to block z = 1 inside the launch as 66 tagged 8-byte granules (the protocol of the
+// SPLIT2 (8..11 rows: 128-176 (row, head) pairs leave half of the CUs without a block): TWO blocks per pair, each over every other
+// round; block z = 0 hands its (m, l, o[64]) to block z = 1 inside the launch as 66 tagged 8-byte granules (the protocol of the
 // batch-1 chain, qkv_attn.hpp: epoch = position * 32 + layer + 1, bounded sweep, error word), which merges the two states in a fixed
 // order and writes the output.  The publishing blocks are dispatched first and never wait.
 constexpr int ATTN_PAIR_GRANULES = 72;                   // 64 x o + m + l, padded
@@ -325,16 +325,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
             qv[e] = t.x; qv[e + 1] = t.y; qv[e + 2] = t.z; qv[e + 3] = t.w;
         }
     }
-    const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
-    const int nr_all = (max(end, 0) + RPOS - 1) / RPOS;
-    // SPLIT2: the publisher (z = 0) takes the upper ceil(n / 2) rounds, the merging block the lower floor(n / 2)
-    const int rbeg = SPLIT2 ? (blockIdx.z == 0 ? nr_all / 2 : 0) : 0;
-    const int nround = SPLIT2 ? (blockIdx.z == 0 ? nr_all - nr_all / 2 : nr_all / 2) : nr_all;
+    // SPLIT2: the rounds alternate between the two blocks -- the merging block (z = 1) takes the even rounds (ceil(n / 2) of them), the
+    // publisher (z = 0) the odd ones -- so each block's FIRST round is known before the row's length is: its keys and values are
+    // requested together with q, ahead of the (dependent) read of the write position.  Positions past the end are masked by the
+    // reduction; what such a slot reads is stale-but-finite cache content (the cache is zeroed at creation, clamped to the plane).
+    const int g0 = SPLIT2 ? (blockIdx.z == 0 ? 1 : 0) : 0;  // first round of this block; round r of the block = round g0 + GS r of the row
+    constexpr int GS = SPLIT2 ? 2 : 1;
     const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
     const KT* vh = vc + (size_t)h * max_seq * 64 + dsub * EPL;
     u32x4 kA[U], vA[U], kB[U], vB[U];
+    {
+        const int base = g0 * RPOS + w * 32 + slot;
+#pragma unroll
+        for (int u = 0; u < U; ++u) kA[u] = ld_stream16(kh + (size_t)min(base + u * PPW, max_seq - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) vA[u] = ld_stream16(vh + (size_t)min(base + u * PPW, max_seq - 1) * 64);
+    }
+    const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
+    const int nr_all = (max(end, 0) + RPOS - 1) / RPOS;
+    const int nround = SPLIT2 ? (blockIdx.z == 0 ? nr_all / 2 : (nr_all + 1) / 2) : nr_all;
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
-        const int base = (rbeg + r) * RPOS + w * 32 + slot;
+        const int base = (g0 + GS * r) * RPOS + w * 32 + slot;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p = base + u * PPW;
@@ -352,14 +363,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
     for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
     const u32x4 none = {0u, 0u, 0u, 0u};
     auto reduce = [&](int r, const u32x4 (&kr)[U], const u32x4 (&vr)[U]) {
-        attn_round_reduce<KT, false>(ss, qv, kr, vr, (rbeg + r) * RPOS + w * 32 + slot, end, -1, none, none);
+        attn_round_reduce<KT, false>(ss, qv, kr, vr, (g0 + GS * r) * RPOS + w * 32 + slot, end, -1, none, none);
     };
     if (round_q) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) qv[e] = H16<KT>::round(qv[e]);
     }
-    if (nround > 0) issue(0, kA, vA);
-    for (int r = 0; r < nround; r += 2) {
+    for (int r = 0; r < nround; r += 2) {                  // (round 0 is already on its way)
         if (r + 1 < nround) issue(r + 1, kB, vB);
         reduce(r, kA, vA);
         if (r + 1 < nround) {
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
             }
             const float O2 = __uint_as_float((unsigned)vo);
             const float M2 = __shfl(__uint_as_float((unsigned)vm), 0, 64), L2 = __shfl(__uint_as_float((unsigned)vm), 1, 64);
-            const float Mx = fmaxf(M, M2), f1 = expf(M - Mx), f2 = expf(M2 - Mx);      // this block's (lower) half first, then the partner's
+            const float Mx = fmaxf(M, M2), f1 = expf(M - Mx), f2 = expf(M2 - Mx);      // this block's rounds first, then the partner's
             L = fmaf(L2, f2, L * f1);
             O = fmaf(O2, f2, O * f1);
         }

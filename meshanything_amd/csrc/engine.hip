@@ -167,6 +167,8 @@ struct ma_engine {
     int opt_profile_batch = 1;       // batch size ma_profile_decode times (<= max_batch)
     int opt_mfma_min_batch = 4;      // bf16 policy: batches of at least this many rows take the MFMA skinny-GEMM decode path
     int opt_attn_pair = 1;               // final-form attention below 12 rows: two blocks per (row, head)
+    int opt_mfma_fc2_ksplit = 0;         // blocks along K of the batched fc2 GEMM: 0 = gemm_dec_ksplit (4) | 1 | 2 | 4
+    int opt_mfma_ln_waves = 0;           // waves per block of the LayerNorm-folded skinny GEMM: 0 = by batch (8 for 5..8 rows, else 4) | 4 | 8
     int opt_mfma_fold_ln = 1;            // MFMA decode path, small batches: LayerNorm prologues inside the consuming GEMMs (up to two launches fewer per layer)
     int opt_mfma_fold_fc1_max = 8, opt_mfma_fold_qkv_max = 8;       // largest batch for which LN1 (in front of fc1) / LN2 (in front of q/k/v) is folded
     int opt_attn_final_min_batch = 8;    // MFMA decode path: from this many rows on, one attention block per (row, head) writes the final output (no merge launch)
@@ -443,7 +445,7 @@ void rows_prologue(ma_engine* e, hipStream_t s, int pro, Rows rw, ProIn in, cons
 void gemm_dec_ln(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kind) {
     if (!tm.on(0)) return;
     a.trace = tm.trace_slot(kind, (a.N + 15) / 16);
-    hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec_ln<HT>(a, s));
+    hipError_t r = H16_CALL(e->hdt, HT, launch_gemm_dec_ln<HT>(a, s, e->opt_mfma_ln_waves));
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec_ln launch failed: ") + hipGetErrorString(r));
 }
 void gemm_dec(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kind) {
@@ -469,7 +471,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     float* partO = e->d_ks_o + 4 * r0 * H; float* partF = e->d_ks_f + 4 * r0 * H;
     (void)MB;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
-    const int ks_o = gemm_dec_ksplit(H, H), ks_f = gemm_dec_ksplit(H, c.ffn);
+    const int ks_o = gemm_dec_ksplit(H, H), ks_f = e->opt_mfma_fc2_ksplit ? e->opt_mfma_fc2_ksplit : gemm_dec_ksplit(H, c.ffn);
     // 4..16 rows: the LayerNorm prologues run inside the consuming GEMMs (gemm_dec_ln_kernel) and out_proj is not split along K, so
     // that its epilogue finishes y1: two launches fewer per layer
     // (the folded prologue reads its inputs once per block: 1 buffer in front of fc1, 4 split-K partials + residual in front of q/k/v, so
@@ -1414,6 +1416,15 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_min_batch") { e->opt_attn_final_min_batch = (int)value; drop_graphs(e); }
         else if (n == "attn_rowwave") { e->opt_attn_rowwave = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_ln") { e->opt_mfma_fold_ln = (int)value; drop_graphs(e); }
+        else if (n == "mfma_fc2_ksplit") {
+            if (value != 0 && value != 1 && value != 2 && value != 4) throw MaError(MA_ERR_INVALID, "mfma_fc2_ksplit must be 0 (default), 1, 2 or 4");
+            if (value > 1 && e->cfg.ffn % (4 * (int)value * 32) != 0) throw MaError(MA_ERR_INVALID, "mfma_fc2_ksplit does not divide the ffn width");
+            e->opt_mfma_fc2_ksplit = (int)value; drop_graphs(e);
+        }
+        else if (n == "mfma_ln_waves") {
+            if (value != 0 && value != 4 && value != 8) throw MaError(MA_ERR_INVALID, "mfma_ln_waves must be 0 (by batch), 4 or 8");
+            e->opt_mfma_ln_waves = (int)value; drop_graphs(e);
+        }
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
@@ -1494,6 +1505,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_final_min_batch") *value = e->opt_attn_final_min_batch;
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else if (n == "mfma_fold_ln") *value = e->opt_mfma_fold_ln;
+        else if (n == "mfma_ln_waves") *value = e->opt_mfma_ln_waves;
+        else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;

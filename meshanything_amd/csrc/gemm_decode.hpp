@@ -190,16 +190,18 @@ __global__ __launch_bounds__(256) void gemm_dec_kernel(GemmDecArgs a) {
 // for the whole weight stream of a launch without prologue (profiles/r04_decode_step_timeline_b8.txt).
 // DEFER: the producer's deferred epilogue (bias `pbias` + residual `pres`, both or neither) is added in front of the LayerNorm -- a
 // template flag, not a branch: requests inside a branch make hipcc wait for them where the branch ends
-template <int PARTS, bool DEFER, typename HT = bf16_t>
-__global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
-    constexpr int K = 1024, CH = 8, XS = K + 16;             // XS: LDS row stride in bf16 elements (32 bytes of padding: conflict-free fragments)
-    __shared__ __attribute__((aligned(16))) float red[4][64][4];
+// NW waves per block (4 | 8): with 8, eight rows are normalised one per wave and ALL their vectors are in flight at once, and each wave
+// streams an eighth of the block's weight rows.
+template <int PARTS, bool DEFER, int NW, typename HT = bf16_t>
+__global__ __launch_bounds__(NW * 64) void gemm_dec_ln_kernel(GemmDecArgs a) {
+    constexpr int K = 1024, KW = K / NW, CH = KW / 32, XS = K + 16;   // XS: LDS row stride in bf16 elements (32 bytes of padding: conflict-free fragments)
+    __shared__ __attribute__((aligned(16))) float red[NW][64][4];
     __shared__ __attribute__((aligned(16))) bf16_t xl[16 * XS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 16;
     gd_stamp(a, 0);
-    const int kbase = w * 256 + kg * 8;
+    const int kbase = w * KW + kg * 8;
     const bf16_t* wrow = a.W + (size_t)min(n0 + m, a.N - 1) * K + kbase;
     // parameters every row shares, and the epilogue's operands (wave 0 finishes the block; lane: batch row m, outputs n0 + 4 kg ..)
     f32x4 gv[4], bv[4], pb[4];
@@ -261,8 +263,18 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     // Loads come back in the order they were asked for (one counter), so the activation rows -- L2 hits -- are asked for BEFORE the block's
     // weight rows -- an HBM stream: the LayerNorm arithmetic then runs while the weights are on their way.
     u32x4 wv[CH];
-    {
-        const int ra_ = w, rb_ = w + 4;                    // rows of the first pass (B <= 8: the only one)
+    int next;                                              // first row of the one-at-a-time tail
+    if constexpr (NW == 8) {                               // one row per wave in the first pass (B <= 8: the only one)
+        const bool one = w < a.B;
+        f32x4 xa[PARTS][4], va[4], sa[4];
+        if (one) request_row(w, xa, va);
+#pragma unroll
+        for (int s = 0; s < CH; ++s) wv[s] = ld_stream16(wrow + s * 32);
+        asm volatile("" ::: "memory");
+        if (one) { sum_row(xa, va, sa); norm_row(w, sa); }
+        next = w + NW;
+    } else {                                               // rows w and w + 4 in the first pass
+        const int ra_ = w, rb_ = w + NW;
         const bool one = ra_ < a.B, two = rb_ < a.B;
         f32x4 xa[PARTS][4], xb2[PARTS][4], va[4], vb[4], sa[4], sb[4];
         if (one) request_row(ra_, xa, va);
@@ -274,8 +286,9 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
         if constexpr (PARTS <= 2) { if (one) sum_row(xa, va, sa); }
         if (one) norm_row(ra_, sa);
         if (two) { sum_row(xb2, vb, sb); norm_row(rb_, sb); }
+        next = w + 2 * NW;
     }
-    for (int r = w + 8; r < a.B; r += 4) {                 // 9 .. 16 rows: one row at a time
+    for (int r = next; r < a.B; r += NW) {                 // more rows: one at a time
         f32x4 xa[PARTS][4], va[4], sa[4];
         request_row(r, xa, va);
         sum_row(xa, va, sa);
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
     if (!e_on) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
 #pragma unroll
-    for (int i = 1; i < 4; ++i) {
+    for (int i = 1; i < NW; ++i) {
         const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][lane][0]);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
@@ -307,16 +320,21 @@ __global__ __launch_bounds__(256) void gemm_dec_ln_kernel(GemmDecArgs a) {
 }
 
 template <typename HT>
-inline hipError_t launch_gemm_dec_ln(const GemmDecArgs& a, hipStream_t s) {
+inline hipError_t launch_gemm_dec_ln(const GemmDecArgs& a, hipStream_t s, int waves = 0) {
     if (a.K != 1024 || a.B < 1 || a.B > 16 || a.ksplit != 1 || !a.pin || !a.ln_g || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) ||
         (a.xn_out && a.xn_stride % 4)) return hipErrorInvalidValue;
     if ((a.pbias != nullptr) != (a.pres != nullptr)) return hipErrorInvalidValue;          // the deferred epilogue comes whole
-    const dim3 grid((a.N + 15) / 16), block(256);
+    const dim3 grid((a.N + 15) / 16);
     const bool d = a.pres != nullptr;
-    if (a.pin_parts == 1 && !d) hipLaunchKernelGGL((gemm_dec_ln_kernel<1, false, HT>), grid, block, 0, s, a);
-    else if (a.pin_parts == 1) hipLaunchKernelGGL((gemm_dec_ln_kernel<1, true, HT>), grid, block, 0, s, a);
-    else if (a.pin_parts == 2 && d) hipLaunchKernelGGL((gemm_dec_ln_kernel<2, true, HT>), grid, block, 0, s, a);
-    else if (a.pin_parts == 4 && d) hipLaunchKernelGGL((gemm_dec_ln_kernel<4, true, HT>), grid, block, 0, s, a);
+    // up to 8 rows: 8 waves, one row each (every vector of every row in flight together); more: 4 waves, rows w, w + 4, ...
+    const bool w8 = waves == 8 || (waves == 0 && a.B <= 8);
+#define MA_GDLN(P, D) do { if (w8) hipLaunchKernelGGL((gemm_dec_ln_kernel<P, D, 8, HT>), grid, dim3(512), 0, s, a); \
+                           else hipLaunchKernelGGL((gemm_dec_ln_kernel<P, D, 4, HT>), grid, dim3(256), 0, s, a); } while (0)
+    if (a.pin_parts == 1 && !d) MA_GDLN(1, false);
+    else if (a.pin_parts == 1) MA_GDLN(1, true);
+    else if (a.pin_parts == 2 && d) MA_GDLN(2, true);
+    else if (a.pin_parts == 4 && d) MA_GDLN(4, true);
+#undef MA_GDLN
     else return hipErrorInvalidValue;                  // (gemm_dec_ksplit gives 1, 2 or 4)
     return hipGetLastError();
 }
@@ -357,13 +375,18 @@ struct RowsProArgs {
 
 // thread t owns the float4 chunks t, t+256, ... of its row: the same partition, arithmetic and summation order as the
 // block-level prologue of gemv_kernel, so a batched row sees the same activation bits as a batch-1 run
-template <int PRO, typename HT = bf16_t>
+// PARTS partial buffers (1 | 2 | 4), DEFER: the producer's deferred bias + residual (both or neither), NCH float4 chunks per thread
+// (1: K <= 1024, 4: K <= 4096) -- template parameters, not branches: every vector of the row is requested before the first is used
+// (one round trip instead of one per vector, profiles/r04_decode_step_timeline_b8.txt), and hipcc waits for the requests made inside a
+// branch where the branch ends.  Chunk indices past the row are clamped for the request and masked at the use.
+template <int PRO, int PARTS, bool DEFER, int NCH, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
     __shared__ float red[8];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x, K = a.K;
-    constexpr int NCH = 4;                               // K <= 4096
-    f32x4 xv[NCH];
+    __shared__ float x0s;
+    const int tid = threadIdx.x, b = blockIdx.x, K = a.K;
+    f32x4 xv[NCH], gv[NCH], bv[NCH];
     const int nq = K / 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (PRO == PRO_ATTN) {
         const int k = tid * 4;
         if (k < K) {
@@ -373,55 +396,45 @@ __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
         }
     } else {
         const float* x = a.x + (size_t)b * a.x_stride;
+        f32x4 pv[PARTS][NCH], bz[NCH], rz[NCH];
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const int idx = tid + 256 * j;
-            xv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(x + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // split-K producer: add the other partials in order, then the deferred epilogue (bias, residual)
-        for (int p = 1; p < a.nparts; ++p) {
-            const float* xp = x + (size_t)p * a.B * a.x_stride;
+            const int ic = min(tid + 256 * j, nq - 1) * 4;
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int idx = tid + 256 * j;
-                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(xp + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            for (int p = 0; p < PARTS; ++p) pv[p][j] = *reinterpret_cast<const f32x4*>(x + (size_t)p * a.B * a.x_stride + ic);
+            if constexpr (DEFER) {
+                bz[j] = *reinterpret_cast<const f32x4*>(a.bias + ic);
+                rz[j] = *reinterpret_cast<const f32x4*>(a.res + (size_t)b * a.res_stride + ic);
+            }
+            if constexpr (PRO == PRO_LN) {
+                gv[j] = *reinterpret_cast<const f32x4*>(a.ln_g + ic);
+                bv[j] = *reinterpret_cast<const f32x4*>(a.ln_b + ic);
             }
         }
-        if (a.bias) {
+        asm volatile("" ::: "memory");
+        // split-K producer: the partials in their order, then the deferred epilogue (bias, residual)
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int idx = tid + 256 * j;
-                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
-            }
-        }
-        if (a.res) {
-            const float* rp = a.res + (size_t)b * a.res_stride;
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 v = pv[0][j];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int idx = tid + 256 * j;
-                if (idx < nq) { const f32x4 t = *reinterpret_cast<const f32x4*>(rp + idx * 4); xv[j].x += t.x; xv[j].y += t.y; xv[j].z += t.z; xv[j].w += t.w; }
+            for (int p = 1; p < PARTS; ++p) { v.x += pv[p][j].x; v.y += pv[p][j].y; v.z += pv[p][j].z; v.w += pv[p][j].w; }
+            if constexpr (DEFER) {
+                v.x += bz[j].x; v.y += bz[j].y; v.z += bz[j].z; v.w += bz[j].w;
+                v.x += rz[j].x; v.y += rz[j].y; v.z += rz[j].z; v.w += rz[j].w;
             }
+            const bool in = tid + 256 * j < nq;
+            xv[j] = in ? v : z4;
+            if constexpr (PRO == PRO_LN) { gv[j] = in ? gv[j] : z4; bv[j] = in ? bv[j] : z4; }
         }
     }
     if constexpr (PRO == PRO_LN) {
-        // element 0 of the (summed) row, computed by every thread exactly as thread 0 computes it: the statistics' shift
-        const float* x = a.x + (size_t)b * a.x_stride;
-        float x0 = x[0];
-        for (int p = 1; p < a.nparts; ++p) x0 += x[(size_t)p * a.B * a.x_stride];
-        if (a.bias) x0 += a.bias[0];
-        if (a.res) x0 += a.res[(size_t)b * a.res_stride];
-        f32x4 gv[NCH], bv[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int idx = tid + 256 * j;
-            gv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(a.ln_g + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bv[j] = idx < nq ? *reinterpret_cast<const f32x4*>(a.ln_b + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        ln_block_onepass<NCH>(xv, gv, bv, x0, tid, nq, K, a.ln_eps, red);
+        // element 0 of the (summed) row -- thread 0 holds it -- is the statistics' shift
+        if (tid == 0) x0s = xv[0].x;
+        __syncthreads();
+        ln_block_onepass<NCH>(xv, gv, bv, x0s, tid, nq, K, a.ln_eps, red);
     }
-    constexpr int NJ = PRO == PRO_ATTN ? 1 : NCH;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int idx = tid + 256 * j;
         if (idx < nq) {
             if (a.xn_out) *reinterpret_cast<f32x4*>(a.xn_out + (size_t)b * a.xn_stride + idx * 4) = xv[j];
@@ -430,13 +443,32 @@ __global__ __launch_bounds__(256) void rows_prologue_kernel(RowsProArgs a) {
     }
 }
 
+template <int PRO, int NCH, typename HT>
+inline hipError_t launch_rows_prologue_v(const RowsProArgs& a, int B, hipStream_t s) {
+    const bool d = a.res != nullptr;
+    const int np = a.nparts < 1 ? 1 : a.nparts;
+    if ((a.bias != nullptr) != d) return hipErrorInvalidValue;                    // the deferred epilogue comes whole
+#define MA_RP(P, D) hipLaunchKernelGGL((rows_prologue_kernel<PRO, P, D, NCH, HT>), dim3(B), dim3(256), 0, s, a)
+    if (np == 1 && !d) MA_RP(1, false);
+    else if (np == 1) MA_RP(1, true);
+    else if (np == 2 && !d) MA_RP(2, false);
+    else if (np == 2) MA_RP(2, true);
+    else if (np == 4 && !d) MA_RP(4, false);
+    else if (np == 4) MA_RP(4, true);
+    else return hipErrorInvalidValue;
+#undef MA_RP
+    return hipGetLastError();
+}
+
 template <typename HT>
 inline hipError_t launch_rows_prologue(const RowsProArgs& a, int pro, int B, hipStream_t s) {
     if (a.K % 4 != 0 || a.K > 4096 || (pro == PRO_ATTN && (a.K > 1024 || a.K != a.attn_heads * 64))) return hipErrorInvalidValue;
-    if (pro == PRO_LN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_LN, HT>), dim3(B), dim3(256), 0, s, a);
-    else if (pro == PRO_ATTN) hipLaunchKernelGGL((rows_prologue_kernel<PRO_ATTN, HT>), dim3(B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((rows_prologue_kernel<PRO_PLAIN, HT>), dim3(B), dim3(256), 0, s, a);
-    return hipGetLastError();
+    if (pro == PRO_ATTN) { hipLaunchKernelGGL((rows_prologue_kernel<PRO_ATTN, 1, false, 1, HT>), dim3(B), dim3(256), 0, s, a); return hipGetLastError(); }
+    if (pro == PRO_LN) {
+        if (!a.ln_g || !a.ln_b) return hipErrorInvalidValue;
+        return a.K <= 1024 ? launch_rows_prologue_v<PRO_LN, 1, HT>(a, B, s) : launch_rows_prologue_v<PRO_LN, 4, HT>(a, B, s);
+    }
+    return a.K <= 1024 ? launch_rows_prologue_v<PRO_PLAIN, 1, HT>(a, B, s) : launch_rows_prologue_v<PRO_PLAIN, 4, HT>(a, B, s);
 }
 
 }  // namespace ma

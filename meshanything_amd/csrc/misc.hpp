@@ -74,14 +74,22 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     // just drops them) -- one memory round trip instead of two in front of the greedy reduction
     float bv = -INFINITY; int bi = 0x7fffffff;
     for (int i = tid; i < nparts; i += 256) { const float v = part_val[i]; const int ix = part_idx[i]; if (arg_better(v, ix, bv, bi)) { bv = v; bi = ix; } }
+    // batched MFMA lm_head (no partials): the first 8192 logits of the row are requested here as well, 32 per thread in one go (clamped
+    // index, masked at the use) -- the greedy sweep below was five dependent round trips of 8 loads each
+    constexpr int PICK_PRE = 32;
+    float pre[PICK_PRE];
+    const bool preloaded = nparts == 0;
+#pragma unroll
+    for (int j = 0; j < PICK_PRE; ++j) pre[j] = logits[preloaded ? min(tid + 256 * j, V - 1) : 0];
     const DecState sv = *st;
     const int do_sample = sv.do_sample;
     if (!do_sample) {
         if (nparts > 0) {            // per-block partials of the lm_head GEMV (eos already excluded there when suppressed): reduced above
         } else {                     // batched MFMA lm_head: plain logits
             const int skip = sv.suppress_eos ? TOK_EOS : -1;
-#pragma unroll 8                                                        // the loads of 8 iterations in flight (the compare chain would serialise them)
-            for (int i = tid; i < V; i += 256) { const float v = logits[i]; if (i != skip && arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
+#pragma unroll
+            for (int j = 0; j < PICK_PRE; ++j) { const int i = tid + 256 * j; if (i < V && i != skip && arg_better(pre[j], i, bv, bi)) { bv = pre[j]; bi = i; } }
+            for (int i = tid + 256 * PICK_PRE; i < V; i += 256) { const float v = logits[i]; if (i != skip && arg_better(v, i, bv, bi)) { bv = v; bi = i; } }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
