@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
     // SPLIT2: the rounds alternate between the two blocks -- the merging block (z = 1) takes the even rounds (ceil(n / 2) of them), the
     // publisher (z = 0) the odd ones -- so each block's FIRST round is known before the row's length is: its keys and values are
     // requested together with q, ahead of the (dependent) read of the write position.  Positions past the end are masked by the
-    // reduction; what such a slot reads is stale-but-finite cache content (the cache is zeroed at creation, clamped to the plane).
+    // reduction and zeroed before it (below); the address is clamped to the plane.
     const int g0 = SPLIT2 ? (blockIdx.z == 0 ? 1 : 0) : 0;  // first round of this block; round r of the block = round g0 + GS r of the row
     constexpr int GS = SPLIT2 ? 2 : 1;
     const KT* kh = kc + (size_t)h * max_seq * 64 + dsub * EPL;
@@ -344,6 +344,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
     const int end = len_override >= 0 ? len_override : st[brow].pos + 1;
     const int nr_all = (max(end, 0) + RPOS - 1) / RPOS;
     const int nround = SPLIT2 ? (blockIdx.z == 0 ? nr_all / 2 : (nr_all + 1) / 2) : nr_all;
+    {   // the early round's slots past the end: whatever the plane held there (a caller's buffer need not be finite) becomes zero --
+        // the reduction masks the score, but 0 x NaN in the value sum would not be 0
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        const int base = g0 * RPOS + w * 32 + slot;
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (base + u * PPW >= end) { kA[u] = zero; vA[u] = zero; }
+    }
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
         const int base = (g0 + GS * r) * RPOS + w * 32 + slot;
 #pragma unroll

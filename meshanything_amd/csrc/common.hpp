@@ -213,8 +213,30 @@ __device__ inline void ln_block_onepass(f32x4 (&xv)[NCH], const f32x4 (&gv)[NCH]
     for (int j = 0; j < NCH; ++j) ln_apply(xv[j], md, rstd, gv[j], bv[j]);
 }
 
+// erf in fp32, both branches evaluated and selected (no divergence): N. Juffa's two minimax polynomials, < 1 ulp over the whole range
+// (checked against scipy's fp64 erf on 3 M points: max abs error 5.8e-8, 0.97 ulp).  The library erff costs several times as much:
+// a GELU epilogue spent as long on it as the tile's whole K loop (profiles/r04_ubench_gemm256_gelu.txt).
+__device__ __forceinline__ float erf_fast(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);      // |a| > 475/512
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
 // exact (erf) GELU, as torch.nn.GELU() / HF "gelu"
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 __device__ inline float apply_act(float v, int act) {

@@ -35,27 +35,41 @@ __global__ void fourier2_kernel(const PT* __restrict__ pc, int n_rows, int F, AT
 
 // nn.LayerNorm over the last dim, one wave per row (two-pass mean / variance in fp32, the row held in registers: one global
 // read, 16-byte accesses): x fp32 -> y32 (fp32, optional) and ya (AT, optional).  y32 may alias x.  D % 4 == 0, D <= 4096.
-template <typename AT>
+// NVT > 0: D == 256 NVT exactly -- every lane owns NVT chunks, no lane-dependent guard: the row's NVT requests and the 2 NVT parameter
+// requests all go out before the first use (hipcc waits for a request made inside a lane-dependent branch where the branch ends: the
+// guarded form, NVT == 0, is one round trip per chunk and streamed 1.8 TB/s; profiles/r04_dense_b64_kernel_stats.csv).
+template <typename AT, int NVT>
 __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__ x, int ldx, RowMap xin, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, float* y32, int ld32, AT* __restrict__ ya,
                                                        int lda, RowMap yout, int rows, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + xin(row) * ldx;
-    constexpr int NV = 16;                                // float4 chunks per lane: D <= 64 * 4 * 16
+    constexpr int NV = NVT > 0 ? NVT : 16;                // float4 chunks per lane: D <= 64 * 4 * 16
     const int nq = D >> 2;
-    f32x4 v[NV];
+    auto in = [&](int j) { return NVT > 0 || lane + 64 * j < nq; };
+    f32x4 v[NV], g4[NV], b4[NV];
     float s = 0.f;
+    if constexpr (NVT > 0) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int q = lane + 64 * j;
-        if (q < nq) { v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * q); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (lane + 64 * j));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { g4[j] = *reinterpret_cast<const f32x4*>(g + 4 * (lane + 64 * j)); b4[j] = *reinterpret_cast<const f32x4*>(b + 4 * (lane + 64 * j)); }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < nq) { v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * q); s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+        }
     }
     const float mean = wave_sum(s) / (float)D;
     float qq = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        if (lane + 64 * j < nq) {
+        if (in(j)) {
             const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
             qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
@@ -65,11 +79,11 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int q = lane + 64 * j;
-        if (q < nq) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * q), b4 = *reinterpret_cast<const f32x4*>(b + 4 * q);
+        if (in(j)) {
+            if constexpr (NVT == 0) { g4[j] = *reinterpret_cast<const f32x4*>(g + 4 * q); b4[j] = *reinterpret_cast<const f32x4*>(b + 4 * q); }
             f32x4 o;
-            o.x = (v[j].x - mean) * rstd * g4.x + b4.x; o.y = (v[j].y - mean) * rstd * g4.y + b4.y;
-            o.z = (v[j].z - mean) * rstd * g4.z + b4.z; o.w = (v[j].w - mean) * rstd * g4.w + b4.w;
+            o.x = (v[j].x - mean) * rstd * g4[j].x + b4[j].x; o.y = (v[j].y - mean) * rstd * g4[j].y + b4[j].y;
+            o.z = (v[j].z - mean) * rstd * g4[j].z + b4[j].z; o.w = (v[j].w - mean) * rstd * g4[j].w + b4[j].w;
             if (y32) *reinterpret_cast<f32x4*>(y32 + orow * ld32 + 4 * q) = o;
             if (ya) {
                 if constexpr (sizeof(AT) == 4) *reinterpret_cast<f32x4*>(ya + orow * lda + 4 * q) = o;
@@ -79,6 +93,16 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
             }
         }
     }
+}
+template <typename AT>
+inline void launch_ln_rows2(const float* x, int ldx, RowMap xin, const float* g, const float* b, float eps, float* y32, int ld32, AT* ya, int lda,
+                            RowMap yout, int rows, int D, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    if (D == 1024) hipLaunchKernelGGL((ln_rows2_kernel<AT, 4>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
+    else if (D == 768) hipLaunchKernelGGL((ln_rows2_kernel<AT, 3>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
+    else if (D == 512) hipLaunchKernelGGL((ln_rows2_kernel<AT, 2>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
+    else if (D == 256) hipLaunchKernelGGL((ln_rows2_kernel<AT, 1>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
+    else hipLaunchKernelGGL((ln_rows2_kernel<AT, 0>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
 }
 
 // out[i][n] = (mask == null || mask[i] ? in[i][n] : 0) + (t0 ? t0[n] : 0) + (tab ? tab[((tab_mod ? i % tab_mod : i) + row0) * ld_tab + n] : 0)
@@ -141,15 +165,26 @@ template <typename KT> __device__ __forceinline__ void store_kv_elem(KT* p, floa
 template <typename AT, typename KT>
 __global__ void kv_fill2_kernel(const AT* __restrict__ src, int ld, int koff, int voff, int rows, int H, int max_seq, KT* __restrict__ kc,
                                 KT* __restrict__ vc, size_t kv_row_stride) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = rows * H * 64;
-    if (idx >= total) return;
     const int b = blockIdx.y;
-    const int d = idx & 63, h = (idx >> 6) % H, r = idx / (64 * H);
-    const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
-    const AT* sp = src + ((size_t)b * rows + r) * ld;
-    if constexpr (sizeof(AT) == sizeof(KT)) { kc[dst] = sp[koff + h * 64 + d]; vc[dst] = sp[voff + h * 64 + d]; }     // same type: plain copy
-    else { store_kv_elem<KT>(kc + dst, (float)sp[koff + h * 64 + d]); store_kv_elem<KT>(vc + dst, (float)sp[voff + h * 64 + d]); }
+    if constexpr (sizeof(AT) == 2 && sizeof(KT) == 2) {                    // same 16-bit format: 16-byte copies, 8 elements per thread
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= rows * H * 8) return;
+        const int d = (idx & 7) * 8, h = (idx >> 3) % H, r = idx / (8 * H);
+        const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
+        const AT* sp = src + ((size_t)b * rows + r) * ld + h * 64 + d;
+        const u32x4 kv = *reinterpret_cast<const u32x4*>(sp + koff), vv = *reinterpret_cast<const u32x4*>(sp + voff);
+        *reinterpret_cast<u32x4*>(kc + dst) = kv;
+        *reinterpret_cast<u32x4*>(vc + dst) = vv;
+    } else {
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        const int total = rows * H * 64;
+        if (idx >= total) return;
+        const int d = idx & 63, h = (idx >> 6) % H, r = idx / (64 * H);
+        const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + r) * 64 + d;
+        const AT* sp = src + ((size_t)b * rows + r) * ld;
+        if constexpr (sizeof(AT) == sizeof(KT)) { kc[dst] = sp[koff + h * 64 + d]; vc[dst] = sp[voff + h * 64 + d]; }     // same type: plain copy
+        else { store_kv_elem<KT>(kc + dst, (float)sp[koff + h * 64 + d]); store_kv_elem<KT>(vc + dst, (float)sp[voff + h * 64 + d]); }
+    }
 }
 
 }  // namespace ma

@@ -281,8 +281,8 @@ GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = 
 void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y32, int ld32, void* ya, int lda, int rows,
             int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}) {
     const float* g = e->PF(prefix + "weight"); const float* b = e->PF(prefix + "bias");
-    if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((ln_rows2_kernel<HT>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<HT*>(ya), lda, yout, rows, D));
-    else hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, s, x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D);
+    if (e->dense16) H16_DO(e->hdt, HT, launch_ln_rows2<HT>(x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<HT*>(ya), lda, yout, rows, D, s));
+    else launch_ln_rows2<float>(x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D, s);
     HIP_CHECK(hipGetLastError());
 }
 // attention over activation tensors; strides in elements; batch = samples (grid.z)
@@ -978,7 +978,7 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
         const std::string p = DEC + "layers." + std::to_string(l) + ".";
         gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE);
         const int n = T * c.heads * 64;
-        if (e->bf16) hipLaunchKernelGGL((kv_fill2_kernel<bf16_t, bf16_t>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, T, c.heads,
+        if (e->bf16) hipLaunchKernelGGL((kv_fill2_kernel<bf16_t, bf16_t>), dim3(ceil_div(n / 8, 256), B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, T, c.heads,
                                         e->maxseq, reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);      // a copy of 16-bit words: either format
         else hipLaunchKernelGGL((kv_fill2_kernel<float, float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const float*>(qkv), 3 * H, H, 2 * H, T, c.heads, e->maxseq,
                                 reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
@@ -1421,6 +1421,10 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
             if (value > 1 && e->cfg.ffn % (4 * (int)value * 32) != 0) throw MaError(MA_ERR_INVALID, "mfma_fc2_ksplit does not divide the ffn width");
             e->opt_mfma_fc2_ksplit = (int)value; drop_graphs(e);
         }
+        else if (n == "mfma_chunks") {
+            if (value != 4 && value != 8) throw MaError(MA_ERR_INVALID, "mfma_chunks must be 4 or 8");
+            gemm_dec_chunks() = (int)value; drop_graphs(e);
+        }
         else if (n == "mfma_ln_waves") {
             if (value != 0 && value != 4 && value != 8) throw MaError(MA_ERR_INVALID, "mfma_ln_waves must be 0 (by batch), 4 or 8");
             e->opt_mfma_ln_waves = (int)value; drop_graphs(e);
@@ -1506,6 +1510,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_rowwave") *value = e->opt_attn_rowwave;
         else if (n == "mfma_fold_ln") *value = e->opt_mfma_fold_ln;
         else if (n == "mfma_ln_waves") *value = e->opt_mfma_ln_waves;
+        else if (n == "mfma_chunks") *value = gemm_dec_chunks();
         else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
@@ -1864,8 +1869,7 @@ int ma_op_gemm_bf16(const void* A, int lda, const void* W, const float* bias, co
 int ma_op_layernorm(const float* x, int ldx, const float* g, const float* b, float eps, float* y, int ldy, int rows, int D, void* stream) {
     return guarded(nullptr, [&] {
         if (!x || !g || !b || !y) throw MaError(MA_ERR_INVALID, "ma_op_layernorm: null pointer");
-        hipLaunchKernelGGL((ln_rows2_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, RowMap{0, 0, 0}, g, b, eps, y, ldy,
-                           (float*)nullptr, 0, RowMap{0, 0, 0}, rows, D);
+        launch_ln_rows2<float>(x, ldx, RowMap{0, 0, 0}, g, b, eps, y, ldy, (float*)nullptr, 0, RowMap{0, 0, 0}, rows, D, reinterpret_cast<hipStream_t>(stream));
         HIP_CHECK(hipGetLastError());
     });
 }

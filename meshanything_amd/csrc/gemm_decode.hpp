@@ -347,6 +347,8 @@ inline int gemm_dec_ksplit(int N, int K) {
     return 1;
 }
 
+inline int& gemm_dec_chunks() { static int v = 8; return v; }      // chunks in flight per wave at 33 .. 64 rows: 8 | 4 (engine option mfma_chunks)
+
 template <typename HT>
 inline hipError_t launch_gemm_dec(const GemmDecArgs& a, hipStream_t s) {
     if (a.ksplit < 1 || a.K % (4 * a.ksplit * 32) != 0 || a.B < 1 || a.B > 64) return hipErrorInvalidValue;
@@ -355,8 +357,13 @@ inline hipError_t launch_gemm_dec(const GemmDecArgs& a, hipStream_t s) {
     const int mt = (a.B + 15) / 16;
     if (mt == 1) hipLaunchKernelGGL((gemm_dec_kernel<1, 8, HT>), grid, block, 0, s, a);
     else if (mt == 2) hipLaunchKernelGGL((gemm_dec_kernel<2, 8, HT>), grid, block, 0, s, a);
-    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3, 4, HT>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_dec_kernel<4, 4, HT>), grid, block, 0, s, a);
+    // 33 .. 64 rows: 8 chunks as well (24 / 32 activation requests per lane besides the 8 weight requests, 154 / 190 registers): the k-range
+    // of a wave (256 in every decode GEMM) is then ONE round trip; with 4 chunks it was two (6.2 us to the last MFMA instead of ~4,
+    // profiles/r04_decode_step_timeline_b64.txt).  gemm_dec_chunks() = 4 restores the shallow form (A/B).
+    else if (mt == 3 && gemm_dec_chunks() == 4) hipLaunchKernelGGL((gemm_dec_kernel<3, 4, HT>), grid, block, 0, s, a);
+    else if (mt == 3) hipLaunchKernelGGL((gemm_dec_kernel<3, 8, HT>), grid, block, 0, s, a);
+    else if (gemm_dec_chunks() == 4) hipLaunchKernelGGL((gemm_dec_kernel<4, 4, HT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_dec_kernel<4, 8, HT>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
