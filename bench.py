@@ -354,7 +354,7 @@ def main():
         # corrected as the MI355X guide prescribes; committed under profiles/): None when no such file is present
         # (a --pmc pass cannot run inside this process: the figure is IMPORTED from the committed profile of the same kernels and labelled so)
         traffic, traffic_source = None, None
-        for name in ("r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
+        for name in ("r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
             f = os.path.join(REPO, "profiles", name)
             if traffic is None and os.path.exists(f) and args.batch == 1 and args.dtype == "bf16" and args.faces == 800:
                 traffic = json.load(open(f)).get("hbm_bytes_per_launch", {}).get(dom)

@@ -138,19 +138,28 @@ __global__ void cvt_rows_kernel(const float* __restrict__ src, int lds, RowMap i
 // get_codes (meshanything.py:178-212) fused with the 'b (nf nv) d -> b nf (nv d)' rearrange (:53) and the face mask (:57), for
 // all faces of the batch: out[f][v*D + d] = sum_{q<3} codebook[ids[f*9 + v*3 + q]][d] (pad -1 contributes 0);
 // mask[f] = all nine ids != -1.  out32 (fp32, optional: ma_get_codes) and outa (AT, optional: the project_down GEMM operand).
+// Four consecutive d per thread (D % 4 == 0): 16-byte gathers from the codebook rows, one 16- / 8-byte store per output.
 template <typename AT>
 __global__ void codes_gather2_kernel(const long long* __restrict__ ids, const float* __restrict__ codebook, int D, int nf, float* __restrict__ out32,
                                      AT* __restrict__ outa, unsigned char* __restrict__ mask) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nf * 3 * D) return;
-    const int f = idx / (3 * D), rem = idx - f * 3 * D, v = rem / D, d = rem - v * D;
+    const int D4 = D >> 2;
+    if (idx >= nf * 3 * D4) return;
+    const int f = idx / (3 * D4), rem = idx - f * 3 * D4, v = rem / D4, d = (rem - v * D4) * 4;
     const long long* ip = ids + (size_t)f * 9 + v * 3;
-    float c[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { const long long id = ip[q]; c[q] = id < 0 ? 0.f : codebook[(size_t)id * D + d]; }
-    const float sum = (c[0] + c[1]) + c[2];
-    if (out32) out32[idx] = sum;
-    if (outa) st_act<AT>(outa + idx, sum);
+    const long long i0 = ip[0], i1 = ip[1], i2 = ip[2];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 c0 = i0 < 0 ? z : *reinterpret_cast<const f32x4*>(codebook + (size_t)i0 * D + d);
+    const f32x4 c1 = i1 < 0 ? z : *reinterpret_cast<const f32x4*>(codebook + (size_t)i1 * D + d);
+    const f32x4 c2 = i2 < 0 ? z : *reinterpret_cast<const f32x4*>(codebook + (size_t)i2 * D + d);
+    f32x4 sum;
+    sum.x = (c0.x + c1.x) + c2.x; sum.y = (c0.y + c1.y) + c2.y; sum.z = (c0.z + c1.z) + c2.z; sum.w = (c0.w + c1.w) + c2.w;
+    const size_t o = (size_t)f * 3 * D + (size_t)v * D + d;
+    if (out32) *reinterpret_cast<f32x4*>(out32 + o) = sum;
+    if (outa) {
+        if constexpr (sizeof(AT) == 4) *reinterpret_cast<f32x4*>(outa + o) = sum;
+        else *reinterpret_cast<u32x2*>(outa + o) = pack4<AT>(sum);
+    }
     if (rem == 0 && mask) {
         bool ok = true;
         for (int q = 0; q < 9; ++q) ok = ok && ids[(size_t)f * 9 + q] != -1;

@@ -1139,7 +1139,7 @@ void detok_chunk(ma_engine* e, hipStream_t s, const long long* ids, const float*
     lnrows(e, s, e->w_pf, Wt, TOK + "point_layernorm.", 1e-5f, X, Wt, Xb, Wt, nb * T, Wt, RowMap{0, 0, 0}, cond_out);
     // faces (meshanything.py:53-60): codes -> project_down -> zero masked -> + pos -> LN
     {
-        const int total = rowsF * 3 * D;
+        const int total = rowsF * 3 * (D / 4);               // four consecutive d per thread
         if (e->dense16) H16_DO(e->hdt, HT, hipLaunchKernelGGL((codes_gather2_kernel<HT>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
                                         codes ? nullptr : reinterpret_cast<HT*>(e->a_fein), e->w_mask));
         else hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, ids, e->PF(DEC + "quantize_codebooks"), D, rowsF, (float*)nullptr,
@@ -1742,7 +1742,7 @@ int ma_get_codes(ma_engine* e, const int64_t* ids, int B, float* codes, void* st
         const int D = e->cfg.codebook_dim, nf = e->nf;
         for (int b0 = 0; b0 < B; b0 += e->dense_rows) {
             const int nb = std::min(e->dense_rows, B - b0);
-            hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(nb * nf * 3 * D, 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(ids) + (size_t)b0 * nf * 9,
+            hipLaunchKernelGGL((codes_gather2_kernel<float>), dim3(ceil_div(nb * nf * 3 * (D / 4), 256)), dim3(256), 0, s, reinterpret_cast<const long long*>(ids) + (size_t)b0 * nf * 9,
                                e->PF(DEC + "quantize_codebooks"), D, nb * nf, codes + (size_t)b0 * nf * 3 * D, (float*)nullptr, e->w_mask);
             HIP_CHECK(hipGetLastError());
         }

@@ -11,7 +11,10 @@ here, so this module restates the two things it is used for, in numpy:
   trimesh's `sample_surface` follows.  Draws come from the GLOBAL numpy RNG, like every other random choice of the reference's
   input side (main.py:129-133 seeds it), in the order faces -> barycentric pairs.
 
-Parity: *unpinned* (no trimesh here to generate fixtures; trimesh releases also differ in how they draw).  What is tested instead
+Parity: *unpinned* -- the draws are NOT trimesh's.  The order follows what trimesh 4.2.3 (the reference's pin) publishes for
+`sample_surface` (`random(count)` for the faces, then `random((count, 2, 1))` for the barycentric pairs, both from the global numpy RNG),
+but there is no trimesh here to generate fixtures, and the face areas / their cumulative sums may round differently: treat the sampled
+cloud as this package's own, statistically equivalent, not draw-for-draw equal.  What is tested instead
 (tests/test_mesh_input.py) are the properties the rest of the path relies on: points on the surface, unit normals of the face under
 each point, density proportional to area, identical geometry through every file format.
 
