@@ -67,5 +67,14 @@ timeout 600 python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > g
 echo "== torchrun, 1 rank (RCCL arena broadcast path)"
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --no-batched-table > gpurun_out/r04_torchrun1.json 2> gpurun_out/r04_torchrun1.err
 cut -c1-300 gpurun_out/r04_torchrun1.json; echo
-echo "== step timeline (batch 1)"
+echo "== kernel stats of the batch-8 bench"
+cd /tmp; rm -rf /tmp/prof8
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof8 -o r4 --output-format csv -- python $R/bench.py --batch 8 --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/r04_prof_b8.json 2> $R/gpurun_out/r04_prof_b8.log
+for f in $(find /tmp/prof8 -name "*kernel_stats*.csv"); do cp $f $R/gpurun_out/r04_bench_batch8_kernel_stats.csv; done
+head -8 $R/gpurun_out/r04_bench_batch8_kernel_stats.csv | cut -c1-200
+cd $R
+echo "== dense phases"
+timeout 300 python scripts/prof_dense.py --batches 16,64 --iters 3 2>&1 | grep dense | tee gpurun_out/r04_dense_phases_final.txt
+echo "== step timeline (batch 8, then batch 1)"
+timeout 300 python scripts/trace_step.py --batch 8 --lens 300,3858 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_trace_b8_final.log; tail -16 gpurun_out/r04_trace_b8_final.log
 timeout 300 python scripts/trace_step.py --lens 300,3800,7400 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_trace_b1.log; tail -40 gpurun_out/r04_trace_b1.log
