@@ -213,6 +213,52 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [8, 16])
+@pytest.mark.parametrize("policy", ["bf16", "fp16"])
+def test_350m_batched_decode_along_the_reference_path(policy, B, golden_dir):
+    """The batched decode path (skinny matrix-core GEMMs with / without the LayerNorm folded in, final-form attention in its two-block and
+    one-block forms, launched row prologues: 8 and 16 rows) against the REFERENCE's own logits: rows 0 .. B - 1 carry the anchor's cloud and
+    are teacher-forced along the reference's greedy path (`dva`, 257 steps, 75 distinct ids); every row's logits stay within the policy's
+    bound of the reference's on every step, and argmax equals the reference's wherever its margin is decisive.  (The batch-1 tests above
+    cover the fused launches; this one holds the kernels that a `--gpus N` run executes to the same numbers.)"""
+    from meshanything_amd.engine import Engine
+    a = dict(np.load(os.path.join(golden_dir, "full_anchor_hf.npz")))
+    d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
+    tag = "dva"
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=B)
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init="diverse")
+    x = torch.from_numpy(d["mouse_norm"])[None].expand(B, -1, -1).contiguous().cuda()
+    _, prefix = eng.encode(x)
+    ref_tok = a[f"{tag}_tokens"]
+    n = len(ref_tok)
+    forced = torch.from_numpy(ref_tok)[None].expand(B, -1).contiguous()
+    toks, lengths, logits = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True)
+    assert toks.shape == (B, n) and all(int(l) == n for l in lengths)
+    top_i = torch.from_numpy(a[f"{tag}_top_idx"]).long().cuda()
+    top_v = torch.from_numpy(a[f"{tag}_top_val"]).cuda()
+    cols = torch.from_numpy(a[f"{tag}_cols"]).long().cuda()
+    lcols = torch.from_numpy(a[f"{tag}_logits_cols"]).cuda()
+    margin = torch.from_numpy(a[f"{tag}_margin"]).cuda()
+    bound = PATH_BOUND[policy]
+    decisive = margin > 2 * bound
+    worst, agree = 0.0, 1.0
+    for b in range(B):
+        lg = logits[b]
+        err = torch.maximum((lg.gather(1, top_i) - top_v).abs().max(dim=1).values, (lg[:, cols] - lcols).abs().max(dim=1).values)
+        worst = max(worst, float(err.max()))
+        lg2 = lg.clone()
+        lg2[:, 1] = float("-inf")
+        arg = lg2.argmax(dim=1)
+        agree = min(agree, float((arg == top_i[:, 0]).float().mean()))
+        assert float(err.max()) <= bound, f"row {b}, step {int(err.argmax())}: logits differ from the reference's by {float(err.max()):.4f}"
+        assert bool((arg[decisive] == top_i[decisive, 0]).all()), f"row {b}: argmax differs from the reference's at a decisive margin"
+        assert torch.equal(toks[b], arg), "the pick kernel's token is not the argmax of the logits it returned"
+    print(f"[{policy}/batch {B}] matrix-core decode path, {B} rows x {n} steps along the reference's greedy path: max abs logit error {worst:.5f} "
+          f"(bound {bound}); lowest argmax agreement of a row {agree * 100:.2f} %")
+    eng.close()
+
+
 def test_forced_tokens_walk_the_given_stream_tiny():
     """ma_sample_cfg.forced_tokens / logits_out on the tiny shape, every decode path (batch 1 chain, rows in the grid, matrix-core batch):
     forcing the engine's OWN greedy stream reproduces it and its logits; forcing another stream reports, at every step, the argmax of
