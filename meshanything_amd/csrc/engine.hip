@@ -484,9 +484,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         const float* resid;
         ProIn qin;                                              // input of this layer's q/k/v GEMM when its LayerNorm is folded
         if (l == 0) {
-            ProIn in; in.x = x_embed;
-            rows_prologue(e, s, PRO_PLAIN, rw, in, nullptr, nullptr, nullptr, tm);
-            resid = x_embed;
+            resid = x_embed;                                    // (its 16-bit copy xb was written by the embedding launch)
         } else {
             ProIn in;
             if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[l - 1].fc2_b; in.res = h1; } else in.x = y2;
@@ -824,6 +822,8 @@ void enqueue_decode_step(ma_engine* e, hipStream_t s, int len_override, StepTime
         a.epi = EPI_EMBED; a.codebook = e->PF(DEC + "quantize_codebooks"); a.extra = e->PF(DEC + "extra_embeds.weight");
         a.tokpos = e->PF(DEC + "token_embed_positions.weight"); a.cond = e->PF(DEC + "cond_embed.weight");
         a.postab = e->PF(DEC + "embed_positions.weight"); a.T = e->T;
+        // batched matrix-core step: the embedding launch also leaves the 16-bit operand of layer 0's q/k/v GEMM (no prologue launch for it)
+        if (use_mfma_decode(e, rw.B)) { a.yb = e->d_xb + (size_t)rw.r0 * H; a.yb_stride = H; }
         a.trace = tm.trace_slot(0, gemv_blocks(e, a.N, a.K));
         if (tm.on(0)) gemv(e, a, s, rw.B);
     }

@@ -37,6 +37,7 @@ struct GemvArgs {
     float* xn_out;          // prologue(x) before rounding, written once by block 0 when non-null: the residual for a later epilogue
     const float* res;       // [N] residual added after the activation, or null
     float* y;               // [N]
+    void* yb; int yb_stride; // EPI_EMBED, 16-bit policies: the same output rounded to WT as well (the batched step's first q/k/v GEMM operand), or null
     int N, K, act, round_x, epi;
     // EPI_QKV: rows [0,H) -> y (q, fp32); [H,2H) -> K cache; [2H,3H) -> V cache at position st->pos
     void* kcache; void* vcache; int H; int max_seq;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
             e += e_t2;
             e += e_t3;
             a.y[my_row] = e;
+            if constexpr (sizeof(WT) == 2) { if (a.yb) store_kv<WT>(reinterpret_cast<WT*>(a.yb) + (size_t)brow * a.yb_stride + my_row, e); }
         } else {
             v += e_bias;                                   // e_bias / e_res are 0 when absent
             v = apply_act(v, a.act);
