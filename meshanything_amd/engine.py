@@ -195,6 +195,7 @@ class Engine:
         ngen = C.c_int32()
         self._check(self.lib.ma_generate(self.h, _ptr(prefix), B, C.byref(sc), _ptr(tokens), lengths, C.byref(ngen), _stream_ptr()))
         del keep
+        self._warn_if_fell_back()
         if return_logits:
             return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32), logits[:, :ngen.value]
         return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32)
@@ -258,6 +259,7 @@ class Engine:
         self._check(self.lib.ma_forward(self.h, _ptr(x), dt, B, C.byref(sc), _ptr(coords), _ptr(tokens), lengths, C.byref(ngen),
                                         _ptr(ids), _ptr(latents), _stream_ptr()))
         del keep
+        self._warn_if_fell_back()
         return {"coords": coords, "tokens": tokens[:, :ngen.value], "lengths": np.array(list(lengths), dtype=np.int32),
                 "ids": ids, "latents": latents}
 
@@ -298,6 +300,17 @@ class Engine:
         return {"launches": {n: kt.launches[i] for i, n in enumerate(names)}, "ms": {n: kt.ms[i] for i, n in enumerate(names)},
                 "step_ms_graph": kt.step_ms_graph, "step_ms_eager": kt.step_ms_eager, "steps": steps, "kv_len": kv_len}
 
+
+    def _warn_if_fell_back(self) -> None:
+        """One line when a generation lost its fused decode launches (an in-launch exchange timed out: another tenant held the CUs) and ran
+        on the five-launch chain instead -- same tokens, a slower step; the engine re-arms the fused launches after 16 clean generations."""
+        n = self.get_option("chain_fallbacks")
+        seen = getattr(self, "_fallbacks_seen", 0)
+        if n > seen:
+            import warnings
+            warnings.warn(f"meshanything_amd: the fused decode launches timed out {n - seen} time(s) (shared device?); the generation re-ran on "
+                          f"the launch chain (same results, slower decode step); chain_fallbacks = {n}", RuntimeWarning, stacklevel=3)
+            self._fallbacks_seen = n
 
     def trace_decode(self, kv_len: int, max_launches: int = 160, max_blocks: int = 2560) -> Dict[str, np.ndarray]:
         """In-kernel timeline of one eager decode step (diagnostics): ticks of the 100 MHz real-time counter."""

@@ -209,7 +209,8 @@ def test_fused_launches_fall_back_when_the_device_is_shared(eng):
     # 256 blocks still fit; a 250-CU hog starves every kernel of the other stream until it ends.)
     eng.occupy_cus(224, 2_000_000, stream=side, release=release)
     try:
-        got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
+        with pytest.warns(RuntimeWarning, match="fused decode launches timed out"):       # the Python handle says so, once per event
+            got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
     finally:
         release[0] = 1
     t1 = time.time()
