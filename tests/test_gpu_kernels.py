@@ -586,16 +586,21 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
         Cb = torch.zeros(M, N, dtype=h16.tdt) if out in ("bf16", "both") else None
         run(Cf, Cb)
         torch.cuda.synchronize()
+        def where(bad):                                  # (a failure of this test was seen once without its message: say everything)
+            idx = bad.nonzero()
+            return f"mode {mode}: {int(bad.sum())} elements, rows {int(idx[:, 0].min())}..{int(idx[:, 0].max())}, cols {int(idx[:, 1].min())}..{int(idx[:, 1].max())}, first {idx[0].tolist()}"
         if Cf is not None:
-            assert not torch.isnan(Cf).any()
-            assert float((Cf - ref).abs().max()) / scale < 3e-5, (mode, float((Cf - ref).abs().max()) / scale)
+            assert not torch.isnan(Cf).any(), "NaN left in the fp32 output: " + where(torch.isnan(Cf))
+            e32 = (Cf - ref).abs() / scale
+            assert float(e32.max()) < 3e-5, f"fp32 output off by {float(e32.max()):.3e}: " + where(e32 >= 3e-5)
         if Cb is not None:
-            assert float((Cb.float() - ref).abs().max()) / scale < 6e-3
+            e16 = (Cb.float() - ref).abs() / scale
+            assert float(e16.max()) < 6e-3, f"16-bit output off by {float(e16.max()):.3e}: " + where(e16 >= 6e-3)
             if Cf is not None:
-                assert torch.equal(Cb, Cf.to(h16.tdt))
+                assert torch.equal(Cb, Cf.to(h16.tdt)), "16-bit copy is not the rounded fp32 output: " + where(Cb != Cf.to(h16.tdt))
         if mode == 1 and 1 in res:
             for a_, b_ in zip(res[1], (Cf, Cb)):
-                assert a_ is None or torch.equal(a_, b_), "the 256 x 256 kernel is not bit-stable from launch to launch"
+                assert a_ is None or torch.equal(a_, b_), "the 256 x 256 kernel is not bit-stable from launch to launch: " + where(a_ != b_)
         res[mode] = (Cf, Cb)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for _ in range(2):
@@ -610,7 +615,7 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
     # computes (a tail of <= 64 rows goes to the skinny GEMM of the batched decode step, whose four waves split K)
     same_rows = M - (M % 256 if M % 256 <= 64 else 0)
     for a_, b_ in zip(res[0], res[1]):
-        assert a_ is None or torch.equal(a_[:same_rows], b_[:same_rows]), "256 x 256 and 128-row tiles disagree bitwise"
+        assert a_ is None or torch.equal(a_[:same_rows], b_[:same_rows]), "256 x 256 and 128-row tiles disagree bitwise: " + str(int((a_[:same_rows] != b_[:same_rows]).sum())) + " elements"
     fl = 2.0 * M * N * K
     print(f"[gemm256 {h16.name}] M {M} N {N} K {K} act {act} res {use_res} out {out}: 256x256 {res[('us', 1)]:.1f} us = {fl / res[('us', 1)] * 1e-6:.1f} TFLOP/s | "
           f"128-row tiles {res[('us', 0)]:.1f} us = {fl / res[('us', 0)] * 1e-6:.1f} TFLOP/s | ratio {res[('us', 0)] / res[('us', 1)]:.2f}x")
