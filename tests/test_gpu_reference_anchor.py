@@ -213,11 +213,11 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize("B", [8, 16])
+@pytest.mark.parametrize("B", [8, 16, 40, 64])
 @pytest.mark.parametrize("policy", ["bf16", "fp16"])
 def test_350m_batched_decode_along_the_reference_path(policy, B, golden_dir):
     """The batched decode path (skinny matrix-core GEMMs with / without the LayerNorm folded in, final-form attention in its two-block and
-    one-block forms, launched row prologues: 8 and 16 rows) against the REFERENCE's own logits: rows 0 .. B - 1 carry the anchor's cloud and
+    one-block forms, launched row prologues, one to four 16-row batch tiles per block: 8, 16, 40 and 64 rows) against the REFERENCE's own logits: rows 0 .. B - 1 carry the anchor's cloud and
     are teacher-forced along the reference's greedy path (`dva`, 257 steps, 75 distinct ids); every row's logits stay within the policy's
     bound of the reference's on every step, and argmax equals the reference's wherever its margin is decisive.  (The batch-1 tests above
     cover the fused launches; this one holds the kernels that a `--gpus N` run executes to the same numbers.)"""
