@@ -458,7 +458,8 @@ void gemm_dec(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kin
 // The 24 OPT layers + lm_head of one decode step for a batch on the matrix cores (gemm_decode.hpp).  Same data flow as the
 // GEMV path; the prologues are one-block-per-row launches, and the two N = hidden GEMMs (out_proj, fc2) are split along K
 // with their bias / residual folded into the LayerNorm prologue that follows them.
-//   layer input:  l == 0: the embedding (plain);  l > 0: LN2_{l-1}(h1 + fc2 partials + b2)  -> h0 (fp32 residual), xb (bf16)
+//   layer input:  l == 0: the embedding (its 16-bit copy xb comes from the embedding launch itself);  l > 0: LN2_{l-1}(h1 + fc2 partials + b2)
+//                 -> h0 (fp32 residual), xb (16-bit) -- inside the q/k/v GEMM up to 8 rows (gemm_dec_ln_kernel), else by a rows_prologue launch
 void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int len_override, StepTimer& tm, Rows rw) {
     const ma_config& c = e->cfg;
     const int H = c.hidden, B = rw.B, L = c.layers;

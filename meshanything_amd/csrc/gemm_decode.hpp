@@ -11,7 +11,9 @@
 // rows (out_proj, fc2: N = 1024 -> 64 row tiles) are also split along K over KS blocks so that every CU streams; a split
 // launch writes raw fp32 partials [KS][B][N] and its bias / residual / LayerNorm happen in the next `rows_prologue_kernel`,
 // which sums the KS partials in fixed order first.  All loads of a chunk (weights AND activations) are issued before its
-// first MFMA.
+// first MFMA; the epilogue's operands (bias, residual, write position) are requested in front of them (gd_epi_request).
+// Every kernel of this file asks for ALL it reads before it uses any of it, with clamped indices and template parameters instead of
+// branches around the requests: hipcc waits for a request made inside a lane-dependent branch where the branch ends.
 //
 // The prologues that the batch-1 GEMV runs per block (LayerNorm of the post-LN residual stream, merge of the split-KV
 // attention partials) would be repeated per block for every batch row here, so they run once per row in
