@@ -62,12 +62,15 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(AttnArgs a) {
     float qf[32];
     {
         const float* qp = Qf + (size_t)(qok ? qrow : 0) * a.q_rs;
+        // (rows past Sq read row 0 and are never stored.  A guard around each request -- `if (qok) t = load` -- made hipcc wait for every one of
+        //  the 16 before issuing the next: sixteen dependent round trips in front of a block's first tile.)
+        f32x4 t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = *reinterpret_cast<const f32x4*>(qp + 4 * c);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (qok) t = *reinterpret_cast<const f32x4*>(qp + 4 * c);
-            qf[2 * c] = rnd(hi ? t.y : t.x);
-            qf[2 * c + 1] = rnd(hi ? t.w : t.z);
+            qf[2 * c] = rnd(hi ? t[c].y : t[c].x);
+            qf[2 * c + 1] = rnd(hi ? t[c].w : t[c].z);
         }
     }
     int kv_end = a.Sk;
@@ -79,12 +82,12 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(AttnArgs a) {
         const int kv0 = t << 5;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int id = tid + NT * i, r = id >> 4, c = id & 15;
-            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if ((NT * NCH == 512 || id < 512) && kv0 + r < a.Sk) {
-                kreg[i] = *reinterpret_cast<const f32x4*>(Kf + (size_t)(kv0 + r) * a.k_rs + 4 * c);
-                vreg[i] = *reinterpret_cast<const f32x4*>(Vf + (size_t)(kv0 + r) * a.v_rs + 4 * c);
-            }
+            // clamped, not guarded (see above): chunks past 512 repeat chunk 511 and are not stored; key rows past Sk repeat the last row
+            // and are masked by the softmax (key <= klimit), their probabilities are exact zeros in front of finite values
+            const int id = min(tid + NT * i, 511), r = id >> 4, c = id & 15;
+            const size_t kr = (size_t)min(kv0 + r, a.Sk - 1);
+            kreg[i] = *reinterpret_cast<const f32x4*>(Kf + kr * a.k_rs + 4 * c);
+            vreg[i] = *reinterpret_cast<const f32x4*>(Vf + kr * a.v_rs + 4 * c);
         }
     };
     auto lstore = [&]() {

@@ -103,13 +103,11 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
     // Q^T fragments: B[k = d][n = query]: lane (query ln, k group hi) holds d = 16 s + 8 hi .. + 7 for the four 16-deep steps
     u32x4 qf[4];
     {
+        // (rows past Sq read row 0 and are never stored: no lane-dependent branch around a request -- hipcc waits for the data where such
+        //  a branch ends)
         const bf16_t* qp = Qp + (size_t)(qok ? qrow : 0) * a.q_rs + 8 * hi;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (qok) v = *reinterpret_cast<const u32x4*>(qp + 16 * s);
-            qf[s] = v;
-        }
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const u32x4*>(qp + 16 * s);
     }
     int kv_end = a.Sk;
     if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + RB - 1, a.Sq - 1) + 1);
@@ -118,14 +116,15 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
     u32x4 kreg[NCH], vreg[NCH];
     auto gload = [&](int t) {
         const int kv0 = t << 6;
+        // Requests with clamped indices, no branch around them: the guarded form (`if (row < Sk) k = load`) made hipcc wait for tile t + 1
+        // right here, in front of tile t's MFMAs -- the prefetch was not one (ISA: s_waitcnt vmcnt(0) before the first MFMA of every tile;
+        // matrix cores busy 0.20 / 0.09 in the 128- / 96-row kernels).  Key rows past Sk repeat the last row: their scores are masked
+        // below (key <= klimit); V^T is zero-padded by vt_pack_kernel.  Chunks past 512 (NW = 3) repeat chunk 511 and are not stored.
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = id & 7;
-            kreg[i] = u32x4{0u, 0u, 0u, 0u}; vreg[i] = u32x4{0u, 0u, 0u, 0u};
-            if (NT * NCH == 512 || id < 512) {
-                if (kv0 + r < a.Sk) kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)(kv0 + r) * a.k_rs + c * 8);
-                vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)r * a.skp + kv0 + c * 8);
-            }
+            const int id = min(tid + NT * i, 511), r = id >> 3, c = id & 7;
+            kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)min(kv0 + r, a.Sk - 1) * a.k_rs + c * 8);
+            vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)r * a.skp + kv0 + c * 8);
         }
     };
     auto lstore = [&](int stage) {
@@ -147,6 +146,10 @@ __global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
     const float sc2 = a.scale * 1.44269504088896340736f;               // scores in the log2 domain: exp(x) = exp2(x log2 e)
 
     if (nt > 0) { gload(0); lstore(0); }
+    // every request made so far (the Q fragments above all) is retired HERE, on every path: otherwise hipcc's wait-count pass carries "Q may
+    // still be in flight" into the loop (the nt == 0 path skips the waits of lstore) and guards the first MFMAs of EVERY tile with vmcnt(3..0)
+    // -- i.e. waits for the tile t + 1 prefetch it has just issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) gload(t + 1);                                   // flies under this tile's MFMAs
