@@ -105,7 +105,7 @@ typedef struct ma_sample_cfg {
     int32_t max_new_tokens; /* <= 9*n_max_faces + 2; 0 = that maximum */
     int32_t suppress_eos;   /* 1: never emit eos (full-length throughput runs on random weights) */
     int32_t check_every;    /* poll the all-rows-finished flag every this many steps (0 = 64) */
-    int32_t reserved;
+    int32_t logits_first_step; /* with logits_out: the first step whose logits are kept (0 = all); see logits_out */
     uint64_t seed;          /* in-kernel uniform stream when `uniforms` is NULL */
     const float *uniforms;  /* DEVICE (B, max_new_tokens) uniforms in [0,1), or NULL.  Injected uniforms define
                                sampling parity with the oracle (the reference's Philox stream is not reproducible). */
@@ -114,7 +114,9 @@ typedef struct ma_sample_cfg {
      * walks the given stream and `tokens` shows what it would have chosen at every step of it.  A forced eos finishes the row. */
     const int64_t *forced_tokens;   /* DEVICE (B, max_new_tokens) int64, or NULL */
     /* when non-NULL, the logits every generated token was picked from: DEVICE (B, max_new_tokens, codebook_size + 3) fp32, row [b][t] =
-     * the distribution of token t (as returned by ma_engine_read_logits for the last step; eos is NOT masked in the copy) */
+     * the distribution of token t (as returned by ma_engine_read_logits for the last step; eos is NOT masked in the copy).  With
+     * logits_first_step = f > 0 only steps t >= f are kept: DEVICE (B, max_new_tokens - f, vocab), row [b][t - f] (deep-cache parity
+     * checks of large batches: 64 rows x 7202 steps of logits would be 15 GB) */
     float *logits_out;
 } ma_sample_cfg;
 

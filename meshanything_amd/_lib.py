@@ -37,7 +37,7 @@ class TensorDesc(C.Structure):
 
 class SampleCfg(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_float),
-                ("max_new_tokens", C.c_int32), ("suppress_eos", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32),
+                ("max_new_tokens", C.c_int32), ("suppress_eos", C.c_int32), ("check_every", C.c_int32), ("logits_first_step", C.c_int32),
                 ("seed", C.c_uint64), ("uniforms", C.c_void_p), ("forced_tokens", C.c_void_p), ("logits_out", C.c_void_p)]
 
 

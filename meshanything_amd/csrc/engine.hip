@@ -32,6 +32,7 @@
 #include "misc.hpp"
 #include "oproj_fc1.hpp"
 #include "qkv_attn.hpp"
+#include "rows_attn.hpp"
 #include "state.hpp"
 // MA_EXPERIMENTAL (build.py: MA_EXPERIMENTAL=1): the measured-and-rejected decode-step forms -- the persistent one-launch step
 // (persist.hpp), the rows-looped two-launch layer (rows_fused.hpp) and the layer-pair launch (layer_fused.hpp); DESIGN.md records why
@@ -192,6 +193,8 @@ struct ma_engine {
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
+    int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
+    u64 *d_ra_qkv_gran = nullptr, *d_ra_out_gran = nullptr;      // its exchanges: [max_batch][RA_QKV_GRANULES], [max_batch][RA_OUT_GRANULES]
     u64* d_y2_gran = nullptr;        // [max_batch][hidden] granules (y2 handed to the next layer inside a launch)
     u64* d_ffn_gran = nullptr;       // [max_batch][ffn] granules (fc2 in the out_proj + fc1 launch)
     unsigned* d_chain_err = nullptr; unsigned* h_chain_err = nullptr;
@@ -493,6 +496,31 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             else rows_prologue(e, s, PRO_LN, rw, in, e->dl[l - 1].ln2_g, e->dl[l - 1].ln2_b, h0, tm);
             resid = h0;
         }
+        // the two-block final-form attention needs both blocks of every (row, head) resident together: 2 B heads <= CUs (8 rows on an MI355X)
+        // (its hand-over epoch is position * 32 + layer + 1: more than 31 layers would alias the next position's layer 0)
+        const bool pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
+        // 8 rows: LayerNorm 2 + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp) -- three launches per layer instead of five.  Its
+        // exchange epochs come from DecState.pos (no caller-supplied length), its 256 blocks of 8 waves need every CU (pair_ok's gate)
+        const bool fused_attn = e->opt_fuse_rows_attn && pair_ok && B == RA_ROWS && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && len_override < 0 &&
+                                H == 1024 && c.heads == 16 && fold;
+        if (fused_attn) {
+            if (tm.on(1)) {
+                RowsAttnArgs a{};
+                a.Wqkv = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bqkv = w.qkv_b;
+                if (l == 0) { a.xb = xb; a.xb_stride = H; a.res = x_embed; a.res_stride = H; }
+                else {
+                    a.pin = qin.x; a.pin_stride = H; a.pin_parts = qin.nparts; a.pbias = qin.bias; a.pres = qin.res; a.pres_stride = H;
+                    a.ln_g = e->dl[l - 1].ln2_g; a.ln_b = e->dl[l - 1].ln2_b; a.ln_eps = 1e-5f; a.xn_out = h0; a.xn_stride = H;
+                }
+                a.kcache = reinterpret_cast<bf16_t*>(e->kplane(rw.r0, l)); a.vcache = reinterpret_cast<bf16_t*>(e->vplane(rw.r0, l)); a.kv_row_stride = kv_row_elems; a.max_seq = e->maxseq;
+                a.st = e->d_st + r0; a.len_override = len_override; a.layer = l;
+                a.qkv_gran = e->d_ra_qkv_gran + r0 * RA_QKV_GRANULES; a.pair_gran = e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES; a.out_gran = e->d_ra_out_gran + r0 * RA_OUT_GRANULES;
+                a.err = e->d_chain_err; a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.y1 = y1; a.y1_stride = H;
+                a.trace = tm.trace_slot(2, 256);
+                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_attn<HT>(a, c.heads, B, s));
+                if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_attn launch failed: ") + hipGetErrorString(r));
+            }
+        } else {
         {
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1;
@@ -505,9 +533,6 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         }
         // 8..11 rows give only 128-176 (row, head) blocks: enough up to ~8 K cached positions, beyond that (1600-face configuration) the
         // split form streams better (profiles/r02_ab_batched_attention_forms.txt, r02_bench_config5_*)
-        // the pair form needs both blocks of every (row, head) resident together: 2 B heads <= CUs (8 rows on an MI355X)
-        // (its hand-over epoch is position * 32 + layer + 1: more than 31 layers would alias the next position's layer 0)
-        const bool pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
         if (B >= e->opt_attn_final_min_batch && (B >= 12 || pair_ok || e->maxseq <= 8192)) {
             // enough (row, head) pairs to fill the chip: the attention launch finishes the softmax itself and writes xb
             if (tm.on(1)) {
@@ -530,8 +555,9 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             if (ks_o_eff > 1) a.y = partO; else { a.y = y1; a.bias = w.o_b; a.res = resid; a.res_stride = H; }
             gemm_dec(e, s, a, tm, 3);
         }
+        }
         ProIn in1;
-        if (ks_o_eff > 1) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
+        if (ks_o_eff > 1 && !fused_attn) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
         if (!fold1) rows_prologue(e, s, PRO_LN, rw, in1, w.ln1_g, w.ln1_b, h1, tm);
         {
             GemmDecArgs a{};
@@ -1002,7 +1028,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     st.t = 0; st.pos = e->T - 1; st.cur_tok = 0; st.finished = 0;
     st.suppress_eos = sc.suppress_eos; st.do_sample = sc.do_sample; st.top_k = sc.top_k; st.top_p = sc.top_p;
     st.seed = sc.seed; st.uniforms = sc.uniforms; st.row = 0; st.max_new = maxn;
-    st.forced = reinterpret_cast<const long long*>(sc.forced_tokens); st.logits_out = sc.logits_out;
+    st.forced = reinterpret_cast<const long long*>(sc.forced_tokens); st.logits_out = sc.logits_out; st.logits_first = sc.logits_out ? sc.logits_first_step : 0;
     hipLaunchKernelGGL(init_state_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, e->d_st, st, B, e->V);
     HIP_CHECK(hipGetLastError());
     // a word left raised by a call that threw before reading it must not make this generation's sweeps give up early
@@ -1013,6 +1039,8 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipMemsetAsync(e->d_ffn_gran, 0, (size_t)e->cfg.max_batch * e->cfg.ffn * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_attn_pair_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_PAIR_GRANULES * sizeof(unsigned long long), s));
     HIP_CHECK(hipMemsetAsync(e->d_y2_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_ra_qkv_gran, 0, (size_t)e->cfg.max_batch * RA_QKV_GRANULES * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_ra_out_gran, 0, (size_t)e->cfg.max_batch * RA_OUT_GRANULES * sizeof(u64), s));
 #ifdef MA_EXPERIMENTAL
     HIP_CHECK(hipMemsetAsync(e->d_part_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_NCHUNK * RF_PART * sizeof(u64), s));
 #endif
@@ -1031,6 +1059,7 @@ ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
         r.max_new_tokens = e->maxnew;
     }
     if (r.check_every <= 0) r.check_every = 64;
+    if (r.logits_first_step < 0 || r.logits_first_step >= r.max_new_tokens) throw MaError(MA_ERR_INVALID, "logits_first_step must be in [0, max_new_tokens)");
     if (r.do_sample && (r.top_k < 1 || r.top_k > PICK_KMAX)) throw MaError(MA_ERR_INVALID, "top_k must be in [1,64]");
     if (r.do_sample && !(r.top_p > 0.f && r.top_p <= 1.f)) throw MaError(MA_ERR_INVALID, "top_p must be in (0,1]");
     return r;
@@ -1225,6 +1254,9 @@ void build_engine(ma_engine* e) {
     HIP_CHECK(hipMemset(e->d_attn_pair_gran, 0, MB * c.heads * ATTN_PAIR_GRANULES * sizeof(unsigned long long)));
     e->d_y2_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y2_gran, 0, MB * H * sizeof(u64)));
+    e->d_ra_qkv_gran = e->dmalloc<u64>(MB * RA_QKV_GRANULES); e->d_ra_out_gran = e->dmalloc<u64>(MB * RA_OUT_GRANULES);
+    HIP_CHECK(hipMemset(e->d_ra_qkv_gran, 0, MB * RA_QKV_GRANULES * sizeof(u64)));
+    HIP_CHECK(hipMemset(e->d_ra_out_gran, 0, MB * RA_OUT_GRANULES * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
     HIP_CHECK(hipMemset(e->d_ffn_gran, 0, MB * (size_t)c.ffn * sizeof(u64)));
 #ifdef MA_EXPERIMENTAL
@@ -1431,6 +1463,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
             e->opt_mfma_ln_waves = (int)value; drop_graphs(e);
         }
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
+        else if (n == "fuse_rows_attn") { e->opt_fuse_rows_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
@@ -1514,6 +1547,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_chunks") *value = gemm_dec_chunks();
         else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
+        else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;

@@ -304,7 +304,9 @@ template <typename HT>
 inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
-    if (gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && (long)((g.N + 255) / 256) * ((g.M + 255) / 256) < (1L << 24)) {
+    // the 256-row tile's 16-bit-only epilogue (C == nullptr) carries no residual and stores 16 bytes to Cb: such calls take the 128-row tile
+    const bool tile256_ok = !(g.R && !g.C) && (!g.Cb || g.ldcb % 8 == 0);
+    if (tile256_ok && gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && (long)((g.N + 255) / 256) * ((g.M + 255) / 256) < (1L << 24)) {
         const int ntx = (g.N + 255) / 256;
         const bool can_split = g.cmap.grp == 0 && g.r_mod == 0;
         auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles >= n_cus && tiles * 100 >= rounds * n_cus * 88; };

@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
     }
     __syncthreads();
     // parity aid (ma_sample_cfg.logits_out): the distribution token t was picked from, kept for every step
-    if (sv.logits_out && sv.t < sv.max_new) {
-        float* lo = sv.logits_out + (size_t)sv.t * V;
+    if (sv.logits_out && sv.t < sv.max_new && sv.t >= sv.logits_first) {
+        float* lo = sv.logits_out + (size_t)(sv.t - sv.logits_first) * V;
         for (int i = tid; i < V; i += 256) lo[i] = logits[i];
     }
     if (tid == 0) {
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
         if (sv.finished) tok = TOK_PAD;
         if (t < sv.max_new) tokens_out[t] = tok;
         // teacher forcing (ma_sample_cfg.forced_tokens): the pick is reported, the given token is fed
-        if (sv.forced && t < sv.max_new) tok = (int)sv.forced[t];
+        // (an id outside [0, V) would index the codebook / extra-embed tables out of bounds in the next embedding launch: clamped here;
+        //  Engine.generate refuses such a buffer on the host side)
+        if (sv.forced && t < sv.max_new) { const long long f = sv.forced[t]; tok = (int)(f < 0 ? 0 : f >= V ? V - 1 : f); }
         if (tok == TOK_EOS) st->finished = 1;
         st->cur_tok = tok;
         st->t = t + 1;
@@ -214,7 +216,7 @@ __global__ void init_state_kernel(DecState* st, DecState v, int B, int V) {
     v.row += b;
     if (v.uniforms) v.uniforms += (size_t)b * v.max_new;
     if (v.forced) v.forced += (size_t)b * v.max_new;
-    if (v.logits_out) v.logits_out += (size_t)b * v.max_new * V;
+    if (v.logits_out) v.logits_out += (size_t)b * (v.max_new - v.logits_first) * V;
     st[b] = v;
 }
 // used by stepwise prefill / profiling: set the fields one decode step reads (all rows)

@@ -19,7 +19,9 @@ struct DecState {
     int row;                 // batch row (decorrelates the hashed uniform stream)
     int max_new;
     const long long* forced; // (max_new_tokens) tokens of this row to feed instead of the picked ones (teacher forcing), or null
-    float* logits_out;       // (max_new_tokens, V) of this row: the logits of every step, or null
+    float* logits_out;       // (max_new_tokens - logits_first, V) of this row: the logits of every step from logits_first on, or null
+    int logits_first;        // first step kept in logits_out
+    int pad_;
 };
 
 // weights of one OPT decoder layer inside the arena ([3p] OPTDecoderLayer; q/k/v fused into one [3H][H] matrix at load)

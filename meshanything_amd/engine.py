@@ -154,7 +154,7 @@ class Engine:
 
     def _sample_cfg(self, sampling: bool, max_new_tokens: Optional[int], suppress_eos: bool, uniforms: Optional[torch.Tensor],
                     seed: int, check_every: int, top_k: int, top_p: float, forced_tokens: Optional[torch.Tensor] = None,
-                    logits_out: Optional[torch.Tensor] = None) -> Tuple[_lib.SampleCfg, object]:
+                    logits_out: Optional[torch.Tensor] = None, logits_first_step: int = 0) -> Tuple[_lib.SampleCfg, object]:
         sc = _lib.SampleCfg()
         sc.struct_size = C.sizeof(_lib.SampleCfg)
         sc.do_sample = 1 if sampling else 0
@@ -172,14 +172,17 @@ class Engine:
             sc.forced_tokens = keep[-1].data_ptr()
         if logits_out is not None:
             sc.logits_out = logits_out.data_ptr()
+            sc.logits_first_step = int(logits_first_step)
         return sc, keep
 
     def generate(self, prefix: torch.Tensor, sampling: bool = False, max_new_tokens: Optional[int] = None,
                  suppress_eos: bool = False, uniforms: Optional[torch.Tensor] = None, seed: int = 0, check_every: int = 64,
-                 top_k: int = 50, top_p: float = 0.95, forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False):
+                 top_k: int = 50, top_p: float = 0.95, forced_tokens: Optional[torch.Tensor] = None, return_logits: bool = False,
+                 logits_first_step: int = 0):
         """transformer.generate(inputs_embeds=prefix, ...) (meshanything.py:143-162) -> (tokens (B, n_generated), lengths).
         forced_tokens (B, max_new_tokens): teacher forcing -- the returned tokens are the engine's own picks at every step of the GIVEN
-        stream (ma_sample_cfg.forced_tokens).  return_logits: also returns the (B, max_new_tokens, vocab) fp32 logits of every step."""
+        stream (ma_sample_cfg.forced_tokens).  return_logits: also returns the (B, max_new_tokens - logits_first_step, vocab) fp32 logits of
+        every step from `logits_first_step` on."""
         cfg = self.cfg
         prefix = prefix.to(self.device, torch.float32).contiguous()
         B = prefix.shape[0]
@@ -188,8 +191,13 @@ class Engine:
             assert tuple(uniforms.shape) == (B, maxn), (uniforms.shape, (B, maxn))
         if forced_tokens is not None:
             assert tuple(forced_tokens.shape) == (B, maxn), (forced_tokens.shape, (B, maxn))
-        logits = torch.zeros(B, maxn, cfg.vocab, dtype=torch.float32, device=self.device) if return_logits else None
-        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p, forced_tokens, logits)
+            lo, hi = int(forced_tokens.min()), int(forced_tokens.max())
+            if lo < 0 or hi >= cfg.vocab:
+                raise ValueError(f"forced_tokens must lie in [0, {cfg.vocab}), got [{lo}, {hi}]")
+        assert 0 <= logits_first_step < maxn
+        logits = torch.zeros(B, maxn - logits_first_step, cfg.vocab, dtype=torch.float32, device=self.device) if return_logits else None
+        sc, keep = self._sample_cfg(sampling, max_new_tokens, suppress_eos, uniforms, seed, check_every, top_k, top_p, forced_tokens, logits,
+                                    logits_first_step)
         tokens = torch.empty(B, cfg.max_new_tokens, dtype=torch.int64, device=self.device)
         lengths = (C.c_int32 * B)()
         ngen = C.c_int32()
@@ -197,7 +205,7 @@ class Engine:
         del keep
         self._warn_if_fell_back()
         if return_logits:
-            return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32), logits[:, :ngen.value]
+            return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32), logits[:, :max(0, ngen.value - logits_first_step)]
         return tokens[:, :ngen.value], np.array(list(lengths), dtype=np.int32)
 
     def postprocess_tokens(self, results: torch.Tensor) -> torch.Tensor:

@@ -116,8 +116,12 @@ def fix_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
                 seen[g] = True
                 queue.append(g)
                 body.append(g)
+    # 6 x the face's term of the volume integral trimesh evaluates (triangles.mass_properties, integral[0], used by Trimesh.volume and by
+    # fix_inversion's per-group volume): cross_x * (x0 + x1 + x2) with cross = (v1 - v0) x (v2 - v0).  On a CLOSED surface the sum equals
+    # the sum of signed tetrahedron volumes v0 . (v1 x v2); on an open one (MeshAnything's outputs usually are) the two differ -- e.g. a
+    # flat patch parallel to the xy plane has cross_x = 0 and is never reversed, wherever it lies.
     tri = np.asarray(verts)[faces].astype(np.float64)
-    signed6 = np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2]))      # 6 x signed tetrahedron volume per face
+    signed6 = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])[:, 0] * tri[:, :, 0].sum(axis=1)
     multibody = _vertex_body_count(len(verts), faces) > 1
     if multibody and len(groups) != 1:
         for body in groups:                                  # (no group at all: nothing to orient)

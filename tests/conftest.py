@@ -77,8 +77,10 @@ _ORDER = (
     ("test_gpu_pipeline.py", "test_large_batches"),
     ("test_gpu_pipeline.py", "test_weights_"),
     ("test_gpu_persist.py", ""),
+    ("test_gpu_rows_attn.py", ""),
     ("test_gpu_rows_fused.py", ""),
     ("test_gpu_reference_anchor.py", ""),
+    ("test_gpu_long_context.py", ""),
     ("test_gpu_pipeline.py", "[bf16]"),
     ("test_gpu_pipeline.py", "[fp16]"),
     ("test_gpu_pipeline.py", "test_v2_scale"),
@@ -199,3 +201,23 @@ def load_weights_cached(engine, cfg, **kw):
 @pytest.fixture(scope="session")
 def state_dicts():
     return cached_state_dict
+
+
+def mouse_variants(golden_dir, k):
+    import numpy as np
+    import torch
+    """k distinct, non-degenerate clouds: pc_examples/mouse.npy rotated about z then y by fixed angles (normals rotate with the
+    points), re-normalised like Dataset.  (Random-weight models collapse on the synthetic sphere clouds: every logit margin
+    falls below the bf16 noise floor, which makes those rows useless as parity probes at full size.)"""
+    from oracle.meshanything_oracle import normalize_pc
+    base = np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"].astype(np.float32)
+    out = []
+    for i in range(k):
+        az, ay = 0.7 * i, 0.4 * i
+        rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]], dtype=np.float32)
+        ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]], dtype=np.float32)
+        r = ry @ rz
+        pc = np.concatenate([base[:, :3] @ r.T, base[:, 3:] @ r.T], axis=1).astype(np.float32)
+        pc[:, 3:] /= np.linalg.norm(pc[:, 3:], axis=1, keepdims=True)
+        out.append(normalize_pc(pc) if i else np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"])
+    return torch.from_numpy(np.stack(out))

@@ -549,6 +549,63 @@ def golden_anchor_diverse(out, cfg: MAConfig, sd, tag: str, mouse: np.ndarray, m
     print(f"anchor[{tag}] detok: {int(out[f'{tag}_detok_valid'].sum())} valid faces, margin quantiles 1% {np.quantile(m, 0.01):.4f} 50% {np.quantile(m, 0.5):.4f}")
 
 
+def golden_anchor_long(cfg: MAConfig, sd, mouse: np.ndarray, steps: int, path: str, every: int = 600):
+    """FULL-LENGTH reference anchor: the reference's own ShapeOPTDecoder.forward (shape_opt.py:248-438)
+    stepped `steps` times on the `dva` weights exactly as generate() drives it (meshanything.py:140-151: one token per call, tuple
+    KV cache grown by torch.cat, attention mask of T + t ones), greedy, eos suppressed -- position rows up to T + steps + 1 of
+    `embed_positions` (shape_opt.py:359), every face slot of `token_embed_positions` hundreds of times, context lengths to
+    T + steps.  Because the weights of the 800-face and the 1600-face configuration are the same tensors and generate() stops on
+    max_new_tokens only, ONE decode of 14 402 steps is the reference stream of BASELINE configs[1] (its first 7 202 tokens) and of
+    configs[4] (all of it).  Recorded for EVERY step, fp32: the greedy token, the top-8 logits (values + ids), the top-1/top-2
+    margin; at `dense` steps (64 spread over the range + the last 16 of either configuration) the top-16 and every 64th column.
+    Partial results are written every `every` steps (the run takes about two hours on 8 cores)."""
+    import time
+    scratch = {}
+    lat, prefix = golden_encoder(scratch, cfg, sd, "e", mouse, rows=[0])
+    dec, lm_head = build_ref_decoder(cfg, sd)
+    B, T = 1, cfg.cond_length
+    cols = np.arange(0, cfg.vocab, 64)
+    n = steps + 1
+    dense = sorted(set(np.linspace(0, steps, 64).astype(int).tolist()) | set(range(7202 - 16, 7202)) | set(range(steps - 15, steps + 1)))
+    dense = [d for d in dense if 0 <= d <= steps]
+    dpos = {d: i for i, d in enumerate(dense)}
+    toks = np.zeros(n, np.int16); top_i = np.zeros((n, 8), np.int16); top_v = np.zeros((n, 8), np.float32); margin = np.zeros(n, np.float32)
+    d_i = np.zeros((len(dense), 16), np.int16); d_v = np.zeros((len(dense), 16), np.float32); d_c = np.zeros((len(dense), len(cols)), np.float32)
+
+    def record(h, j):
+        lg = (h.float() @ lm_head.T)[0].clone()
+        lg[1] = float("-inf")                                  # suppress_eos (as the throughput configs run)
+        tv, ti = torch.topk(lg, 16)
+        toks[j] = int(ti[0]); top_i[j] = ti[:8].numpy(); top_v[j] = tv[:8].numpy(); margin[j] = float(tv[0] - tv[1])
+        if j in dpos:
+            d_i[dpos[j]] = ti.numpy(); d_v[dpos[j]] = tv.numpy(); d_c[dpos[j]] = lg[cols].numpy()
+        return int(ti[0])
+
+    def save(upto):
+        nd = sum(1 for d in dense if d < upto)
+        np.savez_compressed(path + ".tmp.npz", long_tokens=toks[:upto], long_top_idx=top_i[:upto], long_top_val=top_v[:upto], long_margin=margin[:upto],
+                            long_dense_steps=np.array(dense[:nd], np.int32), long_dense_top_idx=d_i[:nd], long_dense_top_val=d_v[:nd],
+                            long_dense_cols=cols.astype(np.int32), long_dense_logits_cols=d_c[:nd],
+                            long_prefix_cols8=prefix[0, :, :8].numpy(), long_complete=np.array([int(upto == n)]))
+        os.replace(path + ".tmp.npz", path)
+    t0 = time.time()
+    with torch.no_grad():
+        o = dec(inputs_embeds=prefix, attention_mask=torch.ones(B, T, dtype=torch.long), use_cache=True, return_dict=True)
+        pkv = o.past_key_values
+        tok = record(o.last_hidden_state[:, -1], 0)
+        for t in range(1, steps + 1):
+            o = dec(input_ids=torch.tensor([[tok]]), past_key_values=pkv, attention_mask=torch.ones(B, T + t, dtype=torch.long),
+                    use_cache=True, return_dict=True)
+            pkv = o.past_key_values
+            tok = record(o.last_hidden_state[:, -1], t)
+            if t % every == 0 or t == 7201:
+                save(t + 1)
+                print(f"anchor[long] step {t}/{steps}: {time.time() - t0:.0f} s, {len(set(toks[:t + 1].tolist()))} distinct, margin min {margin[:t + 1].min():.5f}", flush=True)
+    save(n)
+    assert len(set(toks.tolist())) >= min(256, n // 8)
+    print(f"anchor[long]: {n} tokens, {len(set(toks.tolist()))} distinct, margin min {margin.min():.5f} 1% {np.quantile(margin, 0.01):.5f} median {np.median(margin):.4f}")
+
+
 def golden_shapeopt_generate(out, cfg: MAConfig, sd):
     """THE OUTERMOST COMPOSITION: the reference's own `ShapeOPT` CausalLM wrapper
     (shape_opt.py:18-178) -> ShapeOPTModel -> ShapeOPTDecoder.forward, driven by the container's `GenerationMixin.generate` with the
@@ -706,7 +763,7 @@ def golden_warpers(out):
 def main():
     _stub_modules()
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("MA_GOLDEN_THREADS", 8)))
     if "--only-shapeopt" in sys.argv:                     # the other fixtures are committed and unchanged
         tiny = MAConfig.tiny()
         g = {}
@@ -720,6 +777,15 @@ def main():
         golden_shapeopt_generate(g, tiny, synthetic_state_dict(tiny, include_unused=True))
         np.savez_compressed(os.path.join(HERE, "shapeopt_generate.npz"), **g)
         print("shapeopt_generate.npz", os.path.getsize(os.path.join(HERE, "shapeopt_generate.npz")) // 1024, "KiB")
+        return
+    if "--only-anchor-long" in sys.argv:                  # one 14 402-step reference decode (dva weights): configs[1] and configs[4] at full length
+        full = MAConfig.full(n_max_faces=1600)
+        mouse = np.load(os.path.join(HERE, "dataset.npz"))["mouse_norm"]
+        steps = int(os.environ.get("MA_GOLDEN_LONG_STEPS", full.max_new_tokens))      # generated tokens = steps + 1 (the prefill's pick first)
+        tag, seed, init, mode = ANCHOR_HF_SETS[0]
+        golden_anchor_long(full, synthetic_state_dict(full, seed=seed, include_unused=True, init=init), mouse, steps - 1,
+                           os.path.join(HERE, "full_anchor_long.npz"))
+        print("full_anchor_long.npz", os.path.getsize(os.path.join(HERE, "full_anchor_long.npz")) // 1024, "KiB")
         return
     if "--only-anchor-hf" in sys.argv:                    # 350M-shape reference numbers on diverse streams (two HF-style weight sets)
         full = MAConfig.full()

@@ -47,3 +47,23 @@ def test_world_size_mismatch_is_refused():
     env = dict(os.environ, RANK="3", WORLD_SIZE="8", LOCAL_RANK="3")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE is 8" in (r.stderr + r.stdout)
+
+
+def test_config_4_is_512_shapes_each_once_with_its_own_uniform_stream():
+    """BASELINE.json configs[3] ("batch 512 synthetic clouds sharded data-parallel over 8 x MI355X") = `bench.py --gpus 8 --batch 64 --sampling`:
+    every rank steps 64 shapes together with top-k / top-p sampling, rank r owns the contiguous block 64 r .. 64 r + 63 (whole batches
+    round-robin over the processes, as accelerate's sampler sharding of main.py:137-146 hands them out), the 8 ranks cover 0 .. 511 exactly
+    once, and every (rank, row) pair has its own uniform stream (the in-kernel stream is keyed by (seed, row, step); the seed is per rank)."""
+    b = _bench()
+    seen, streams = [], set()
+    for rank in range(8):
+        pl = b.plan(gpus=8, batch=64, rank=rank, world=8, sampling=True)
+        assert pl["batch"] == 64 and pl["shapes"] == list(range(64 * rank, 64 * rank + 64)) and pl["global_batch"] == 512
+        assert "configs[3]" in pl["workload"] and "batch 512" in pl["workload"] and "top-k 50 / top-p 0.95" in pl["workload"] and "proper" not in pl["workload"]
+        assert pl["scaling"] == "weak" and pl["parallelism"].startswith("dp8 ")
+        seen += pl["shapes"]
+        streams |= {(pl["seed"], row) for row in range(64)}
+    assert sorted(seen) == list(range(512))
+    assert len(streams) == 512, "two rows of the job would draw from the same uniform stream"
+    # the greedy 8 x N default keeps the same seed plumbing
+    assert len({b.plan(gpus=4, batch=0, rank=r, world=4)["seed"] for r in range(4)}) == 4

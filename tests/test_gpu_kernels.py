@@ -345,6 +345,39 @@ def test_decode_attention_rows(lib, h16, B, length, H, waves):
     assert float((outs[0].float() - h16.rnd(ref)).abs().mean()) < 1e-3
 
 
+@pytest.mark.parametrize("B,length,waves", [(8, 9000, 82), (8, 14659, 82), (8, 14659, 8), (10, 14659, 8), (12, 14659, 4), (64, 7459, 4)])
+def test_decode_attention_rows_deep_cache(lib, h16, B, length, waves):
+    """The final-form decode attention at the cache depths of BASELINE configs 3 and 5 (the kernel test stopped at 2 500
+    positions): 7 459 positions x 64 rows (config 3's last step), 9 000 and 14 659 positions x 8 rows in the two-block form the engine
+    runs at 8 rows (waves 82) and in the one-block forms, 10 / 12 rows at 14 659.  Operands are drawn on the device (the largest case holds
+    3.9 GB of K / V); every (row, head) against an fp64 softmax reference on the same rounded q / K / V; bit-stable across launches; cache rows
+    beyond `length` hold NaN and must not be touched."""
+    H = 16
+    max_seq = length + 3
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + length)
+    q = torch.randn(B, H * 64, generator=g, device="cuda")
+    kd = torch.randn(B, H, max_seq, 64, generator=g, device="cuda").to(h16.tdt)
+    vd = torch.randn(B, H, max_seq, 64, generator=g, device="cuda").to(h16.tdt)
+    kd[:, :, length:] = float("nan"); vd[:, :, length:] = float("nan")
+    outs = []
+    for it in range(2):
+        out = torch.full((B, H * 64), float("nan"), device="cuda", dtype=h16.tdt)
+        _chk(lib, lib.ma_op_decode_attention_rows(_p(q), _p(kd), _p(vd), H, max_seq, length, B, H * max_seq * 64, 8 if waves == 82 else waves, 2 if waves == 82 else 1, _p(out), _stream()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0].float()).any()
+    qb = q.to(h16.tdt).double().reshape(B, H, 64)
+    worst, mean = 0.0, 0.0
+    for b in range(B):                                     # one row at a time: the fp64 copies of a row's K / V are 240 MB
+        kf, vf = kd[b, :, :length].double(), vd[b, :, :length].double()
+        p = torch.softmax(torch.einsum("hd,hsd->hs", qb[b], kf) * 0.125, dim=-1)
+        ref = torch.einsum("hs,hsd->hd", p, vf).reshape(H * 64).float()
+        worst = max(worst, float((outs[0][b].float() - ref).abs().max()))
+        mean += float((outs[0][b].float() - ref.to(h16.tdt).float()).abs().mean()) / B
+    # (a softmax over ~10^4 random scores is nearly flat: outputs are O(0.01-0.1), rounded to 16 bits at the end)
+    assert worst < 2e-3 and mean < 1e-4, (worst, mean)
+
+
 # ---------------------------------------------------------------------------------------------- batched decode step kernels
 @pytest.mark.parametrize("B", [1, 4, 8, 13, 16])
 @pytest.mark.parametrize("N,parts,act,extras", [(3072, 4, 0, True), (4096, 1, 1, True), (4096, 1, 1, False), (1024, 2, 0, True), (8195, 4, 0, True)])

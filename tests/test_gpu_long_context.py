@@ -1,0 +1,214 @@
+"""Deep-cache parity on MI355X: the benchmarked workload pinned END TO END, and BASELINE configs 3 / 5 deep in their caches.
+
+Every reference-produced fixture of the earlier rounds stopped at 257 generated tokens; the benchmark generates 7 202 (meshanything.py:140-151,
+max_new_tokens = 9 F + 2) and the 1 600-face configuration 14 402.  `tests/golden/full_anchor_long.npz` (make_golden.py --only-anchor-long) is ONE
+greedy decode of the REFERENCE's own ShapeOPTDecoder.forward (shape_opt.py:248-438), stepped 14 401 times the way generate() drives it, on the
+`dva` weights and pc_examples/mouse.npy: its first 7 202 tokens are the stream of BASELINE configs[1] (the 800-face and the 1 600-face
+configuration share every weight tensor and generate() stops on max_new_tokens only), all 14 402 the stream of configs[4].  Per step it holds
+the token, the top-8 logits and the top-1 / top-2 margin; at 92 steps (64 spread + the last 16 of either length) the top-16 and every 64th
+column.  Position rows 2 .. 14 661 of `embed_positions` (shape_opt.py:359), every face slot of `token_embed_positions` 1 600 times, cache
+lengths to 14 659.
+
+  * config 2 / config 5 at batch 1: the engine teacher-forced (ma_sample_cfg.forced_tokens + logits_out) along ALL tokens of the reference's
+    stream, every step's logits against the reference's numbers, in all three precision policies; and free-running: the first step at which
+    the engine leaves the reference's stream must be a near-tie of the reference itself.
+  * config 5 batched (8 rows: two-block final-form attention; 10 rows: the split form that the 1 600-face cache selects) and config 3
+    (64 rows, top-k / top-p sampling) teacher-forced to the END of their caches (kv 14 659 / 7 459): row 0 against the reference anchor, every
+    checked row against the fp32 oracle's one-pass teacher-forced logits on torch-ROCm, the sampler's draws against the CDF of the logits they
+    were drawn from.
+Bounds = max abs logit error against fp32 numbers (the reference's, or the fp32-policy oracle's): fp32 2e-3, fp16 1e-2, bf16 8e-2 -- the
+bounds of the 257-step anchors (test_gpu_reference_anchor.py): the error does not grow with the cache length."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
+from conftest import cached_state_dict, load_weights_cached, mouse_variants, oracle_device
+
+pytestmark = pytest.mark.gpu
+POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}
+PATH_BOUND = {"fp32": 2e-3, "bf16": 8e-2, "fp16": 1e-2}
+INIT = "diverse"                                             # the anchor's weights (make_golden.py: ANCHOR_HF_SETS[0])
+
+
+@pytest.fixture(scope="module")
+def anchor(golden_dir):
+    a = dict(np.load(os.path.join(golden_dir, "full_anchor_long.npz")))
+    assert int(a["long_complete"][0]) == 1 and len(a["long_tokens"]) == 14402, "tests/golden/full_anchor_long.npz is a partial run"
+    assert len(set(a["long_tokens"][:7202].tolist())) >= 256
+    return a
+
+
+def _mouse(golden_dir):
+    return torch.from_numpy(np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"])[None]
+
+
+def _against_anchor(lg, a, first, n, policy, what):
+    """lg (n - first, V): the engine's logits of steps first .. n - 1 along the anchor's stream.  Returns a dict of statistics after
+    asserting the bound on every step and the argmax at every decisive step."""
+    dev = lg.device
+    bound = PATH_BOUND[policy]
+    top_i = torch.from_numpy(a["long_top_idx"][first:n].astype(np.int64)).to(dev)
+    top_v = torch.from_numpy(a["long_top_val"][first:n]).to(dev)
+    margin = torch.from_numpy(a["long_margin"][first:n]).to(dev)
+    err = (lg.gather(1, top_i) - top_v).abs().max(dim=1).values
+    ds = a["long_dense_steps"]
+    sel = [(i, int(s)) for i, s in enumerate(ds) if first <= int(s) < n]
+    derr = 0.0
+    if sel:
+        rows = torch.tensor([s - first for _, s in sel], device=dev)
+        di = torch.from_numpy(a["long_dense_top_idx"][[i for i, _ in sel]].astype(np.int64)).to(dev)
+        dv = torch.from_numpy(a["long_dense_top_val"][[i for i, _ in sel]]).to(dev)
+        cols = torch.from_numpy(a["long_dense_cols"].astype(np.int64)).to(dev)
+        dc = torch.from_numpy(a["long_dense_logits_cols"][[i for i, _ in sel]]).to(dev)
+        derr = max(float((lg[rows].gather(1, di) - dv).abs().max()), float((lg[rows][:, cols] - dc).abs().max()))
+    lg2 = lg.clone()
+    lg2[:, 1] = float("-inf")                                 # eos is suppressed in the anchor and in the engine's pick, not in logits_out
+    arg = lg2.argmax(dim=1)
+    del lg2
+    agree = arg == top_i[:, 0]
+    decisive = margin > 2 * bound
+    worst = int(err.argmax())
+    assert float(err.max()) <= bound, f"{what}: step {first + worst}: logits differ from the reference's by {float(err.max()):.4f} (bound {bound})"
+    assert derr <= bound, f"{what}: top-16 / column logits of the dense steps differ by {derr:.4f}"
+    bad = (~agree & decisive).nonzero().flatten()
+    assert bad.numel() == 0, f"{what}: argmax differs from the reference's at decisive margins, first at step {first + int(bad[0])}"
+    thirds = [float(err[i * len(err) // 3:(i + 1) * len(err) // 3].max()) for i in range(3)]
+    return {"max_err": float(err.max()), "median_err": float(err.median()), "dense_err": derr, "agree": float(agree.float().mean()), "arg": arg,
+            "decisive": int(decisive.sum()), "err_by_third": thirds, "n": n - first}
+
+
+@pytest.mark.parametrize("faces,policy", [(800, "bf16"), (800, "fp16"), (800, "fp32"), (1600, "bf16"), (1600, "fp32")])
+def test_full_length_along_the_reference_path(policy, faces, anchor, golden_dir):
+    """BASELINE configs[1] (800 faces: 7 202 tokens, the benchmarked workload) and configs[4]'s shape at batch 1 (1 600 faces: 14 402 tokens),
+    every step against the reference's own decode."""
+    from meshanything_amd.engine import Engine
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=1, n_max_faces=faces)
+    n = cfg.max_new_tokens
+    assert n == (7202 if faces == 800 else 14402)
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=INIT)
+    _, prefix = eng.encode(_mouse(golden_dir).cuda())
+    assert float(np.abs(prefix[0, :, :8].cpu().numpy() - anchor["long_prefix_cols8"]).max()) < 1e-4      # the engine's own (exact) encoder feeds it
+    ref_tok = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
+    toks, lengths, logits = eng.generate(prefix, suppress_eos=True, forced_tokens=ref_tok[None], return_logits=True)
+    assert toks.shape == (1, n) and int(lengths[0]) == n and logits.shape[1] == n
+    r = _against_anchor(logits[0], anchor, 0, n, policy, f"{policy}/{faces} faces")
+    assert torch.equal(toks[0], r["arg"]), "the pick kernel's token is not the argmax of the logits it returned"
+    assert r["agree"] >= {"fp32": 0.998, "fp16": 0.985, "bf16": 0.90}[policy], r["agree"]
+    del logits
+    # free-running: where the engine first leaves the reference's stream, the reference itself must be at a near-tie
+    free, _ = eng.generate(prefix, suppress_eos=True)
+    same = (free[0].cpu() == ref_tok)
+    fork = int((~same).nonzero()[0]) if not bool(same.all()) else n
+    m_fork = float(anchor["long_margin"][fork]) if fork < n else float("inf")
+    print(f"[{policy}/{faces} faces] {n} steps along the reference's greedy stream ({len(set(ref_tok.tolist()))} distinct ids, cache to {cfg.cond_length + n - 1}): "
+          f"max abs logit error {r['max_err']:.5f} (bound {PATH_BOUND[policy]}), median {r['median_err']:.5f}, by third of the stream {['%.5f' % x for x in r['err_by_third']]}, "
+          f"dense steps {r['dense_err']:.5f}; argmax agreement {r['agree'] * 100:.3f} % ({r['decisive']} decisive steps all equal); free-running: first "
+          f"{fork} tokens identical to the reference's" + (f", leaves it at a reference margin of {m_fork:.5f}" if fork < n else " = the whole stream"))
+    assert fork == n or m_fork <= 2 * PATH_BOUND[policy], f"the engine left the reference's stream at step {fork} although the reference's margin there is {m_fork:.4f}"
+    if policy == "fp32":
+        assert fork >= 256
+    eng.close()
+
+
+def _oracle_rows(cfg, prefix, forced, rows, first):
+    """fp32-policy oracle (torch-ROCm), one causal pass per row: logits of steps first .. n - 1 on the forced stream."""
+    from oracle.meshanything_oracle import Oracle
+    ora = Oracle(cfg, cached_state_dict(cfg, init=INIT), "fp32", device=oracle_device())
+    out = {}
+    with ora.on_device():
+        for b in rows:
+            out[b] = ora.teacher_forced_logits(prefix[b:b + 1].cpu(), forced)[first:forced.shape[0]].clone()
+    del ora
+    torch.cuda.empty_cache()
+    return out
+
+
+def _against_oracle(lg, ref, policy, what):
+    bound = PATH_BOUND[policy]
+    err = (lg - ref).abs().max(dim=1).values
+    r2 = ref.clone(); r2[:, 1] = float("-inf")
+    top2 = torch.topk(r2, 2, dim=-1)
+    decisive = (top2.values[:, 0] - top2.values[:, 1]) > 2 * bound
+    l2 = lg.clone(); l2[:, 1] = float("-inf")
+    arg = l2.argmax(dim=1)
+    assert float(err.max()) <= bound, f"{what}: step offset {int(err.argmax())}: logits differ from the fp32 oracle's by {float(err.max()):.4f} (bound {bound})"
+    assert bool((arg[decisive] == top2.indices[decisive, 0]).all()), f"{what}: argmax differs from the oracle's at a decisive margin"
+    return float(err.max()), float((arg == top2.indices[:, 0]).float().mean()), arg
+
+
+@pytest.mark.parametrize("B,first", [(8, 7800), (10, 13800)])
+def test_config5_batched_deep_cache(B, first, anchor, golden_dir):
+    """BASELINE configs[4]: 1 600 faces, a batch stepping together to the END of a 14 659-position cache (8 rows: the engine's two-block
+    final-form attention; 10 rows: more (row, head) pairs than CUs and a cache beyond 8 K -> the split form + merge launch).  Rows are
+    distinct clouds, all teacher-forced along the reference's stream; the logits of steps `first` .. 14 401 (cache 8 057 / 14 057 .. 14 658)
+    of every row against the fp32 oracle on that row's own prefix, row 0 (pc_examples/mouse.npy) also against the reference anchor."""
+    from meshanything_amd.engine import Engine
+    policy = "bf16"
+    cfg = MAConfig.full(dtype=DTYPE_BF16, n_max_faces=1600, max_batch=B)
+    n = cfg.max_new_tokens
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=INIT)
+    _, prefix = eng.encode(mouse_variants(golden_dir, B).cuda())
+    forced = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
+    toks, lengths, logits = eng.generate(prefix, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(), return_logits=True,
+                                         logits_first_step=first)
+    assert toks.shape == (B, n) and logits.shape == (B, n - first, cfg.vocab) and all(int(l) == n for l in lengths)
+    ra = _against_anchor(logits[0], anchor, first, n, policy, f"batch {B}, row 0")
+    assert torch.equal(toks[0, first:], ra["arg"])
+    rows = list(range(B))
+    ref = _oracle_rows(cfg, prefix, forced, rows, first)
+    worst, agree = 0.0, 1.0
+    for b in rows:
+        e, ag, arg = _against_oracle(logits[b], ref[b], policy, f"batch {B}, row {b}")
+        assert torch.equal(toks[b, first:], arg), "the pick kernel's token is not the argmax of the logits it returned"
+        worst, agree = max(worst, e), min(agree, ag)
+    assert len({tuple(logits[b, -1, :64].tolist()) for b in rows}) == B, "rows of distinct clouds produced identical logits"
+    print(f"[config 5: 1600 faces, batch {B}] steps {first} .. {n - 1} (cache {cfg.cond_length + first} .. {cfg.cond_length + n - 1}): row 0 vs the reference's decode max abs logit error "
+          f"{ra['max_err']:.5f}, argmax agreement {ra['agree'] * 100:.2f} %; all {B} rows vs the fp32 oracle {worst:.5f} (bound {PATH_BOUND[policy]}), lowest argmax agreement {agree * 100:.2f} %")
+    eng.close()
+
+
+def test_config3_batch64_deep_cache(anchor, golden_dir):
+    """BASELINE configs[2]: 64 rows, top-k 50 / top-p 0.95 sampling, stepped to the END of the 800-face cache (7 459 positions).  All rows
+    are teacher-forced along the reference's stream (so the context is known), the sampler draws from injected uniforms: the logits of the
+    last 202 steps of rows 0, 8, .., 56 against the fp32 oracle (row 0 also against the reference anchor), and EVERY draw of all 64 rows
+    against the CDF of the very logits it was drawn from (the radix-select sampler deep in the generation)."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import classify_sampled_draws
+    policy, B, first = "bf16", 64, 7000
+    cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=B)
+    n = cfg.max_new_tokens
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=INIT)
+    x = mouse_variants(golden_dir, B)
+    _, prefix = eng.encode(x.cuda())
+    forced = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
+    u = torch.rand(B, n, generator=torch.Generator().manual_seed(640))
+    toks, lengths, logits = eng.generate(prefix, sampling=True, uniforms=u, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(),
+                                         return_logits=True, logits_first_step=first)
+    assert toks.shape == (B, n) and logits.shape == (B, n - first, cfg.vocab)
+    assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab and not bool((toks == 1).any())
+    ra = _against_anchor(logits[0], anchor, first, n, policy, "batch 64, row 0")
+    rows = list(range(0, B, 8))
+    ref = _oracle_rows(cfg, prefix, forced, rows, first)
+    worst = 0.0
+    for b in rows:
+        e, _, _ = _against_oracle(logits[b], ref[b], policy, f"batch 64, row {b}")
+        worst = max(worst, e)
+    lg = logits.reshape(-1, cfg.vocab).clone()
+    lg[:, 1] = float("-inf")
+    c = classify_sampled_draws(lg, toks[:, first:].reshape(-1), u[:, first:].reshape(-1), tol=2e-3)
+    nd = c["ok"].numel()
+    ok, exact = int(c["ok"].sum()), int(c["exact"].sum())
+    d = c["distance"]
+    print(f"[config 3: batch 64, top-k/top-p, steps {first} .. {n - 1} (cache to {cfg.cond_length + n - 1})] row 0 vs the reference's decode: max abs logit error {ra['max_err']:.5f}; rows {rows} vs "
+          f"the fp32 oracle: {worst:.5f} (bound {PATH_BOUND[policy]}); {nd} draws against the CDF of their own logits: {exact} exact, {ok} within 2e-3 of the token's interval, "
+          f"largest distance {float(d[torch.isfinite(d)].max()):.5f}, {int((~torch.isfinite(d)).sum())} outside the top-k neighbourhood")
+    assert int((~torch.isfinite(d)).sum()) == 0
+    assert ok >= 0.999 * nd and exact >= 0.99 * nd, (ok, exact, nd)
+    assert len({tuple(r.tolist()) for r in toks[:, first:].cpu()}) > B // 2, "rows with distinct uniforms drew identical tokens"
+    eng.close()

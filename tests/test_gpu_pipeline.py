@@ -8,7 +8,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
-from conftest import cached_state_dict, load_weights_cached, oracle_device
+from conftest import mouse_variants, cached_state_dict, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 
@@ -28,24 +28,6 @@ def synth_cloud(seed, n):
 def clouds(cfg, seeds):
     from oracle.meshanything_oracle import normalize_pc
     return torch.from_numpy(np.stack([normalize_pc(synth_cloud(s, cfg.n_points)) for s in seeds]))
-
-
-def mouse_variants(golden_dir, k):
-    """k distinct, non-degenerate clouds: pc_examples/mouse.npy rotated about z then y by fixed angles (normals rotate with the
-    points), re-normalised like Dataset.  (Random-weight models collapse on the synthetic sphere clouds: every logit margin
-    falls below the bf16 noise floor, which makes those rows useless as parity probes at full size.)"""
-    from oracle.meshanything_oracle import normalize_pc
-    base = np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"].astype(np.float32)
-    out = []
-    for i in range(k):
-        az, ay = 0.7 * i, 0.4 * i
-        rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]], dtype=np.float32)
-        ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]], dtype=np.float32)
-        r = ry @ rz
-        pc = np.concatenate([base[:, :3] @ r.T, base[:, 3:] @ r.T], axis=1).astype(np.float32)
-        pc[:, 3:] /= np.linalg.norm(pc[:, 3:], axis=1, keepdims=True)
-        out.append(normalize_pc(pc) if i else np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"])
-    return torch.from_numpy(np.stack(out))
 
 
 class Env:

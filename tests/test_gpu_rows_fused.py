@@ -13,7 +13,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16
 from conftest import load_weights_cached
-from test_gpu_pipeline import mouse_variants
+from conftest import mouse_variants
 
 pytestmark = pytest.mark.gpu
 

@@ -85,10 +85,10 @@ COL = " 1.00000000 0.64705882 0.00000000"
 
 
 def test_obj_text_of_a_hand_derived_case(tmp_path):
-    """Vertices in first-occurrence order; face 2 reversed by fix_winding ([::-1] of (2, 3, 4) = (4, 3, 2), 1-based); the open
-    surface at z = +1/4 has 6 V = 0.0625 + 0.0625 > 0 and stays, the same surface at z = -1/4 has 6 V < 0 and is reversed
-    as a whole (np.fliplr of every face)."""
-    for z, faces_txt in ((0.25, ["f 1 2 3", "f 4 3 2"]), (-0.25, ["f 3 2 1", "f 2 3 4"])):
+    """Vertices in first-occurrence order; face 2 reversed by fix_winding ([::-1] of (2, 3, 4) = (4, 3, 2), 1-based).  trimesh's volume is
+    the integral sum(cross_x * (x0 + x1 + x2)) / 6 (triangles.mass_properties): a flat patch parallel to the xy plane has cross_x = 0,
+    volume 0, and is NOT reversed whichever side of the origin it lies on (a sum of signed tetrahedron volumes would reverse it at z < 0)."""
+    for z, faces_txt in ((0.25, ["f 1 2 3", "f 4 3 2"]), (-0.25, ["f 1 2 3", "f 4 3 2"])):
         v, f = faces_from_coords(_square(z))
         f = fix_normals(v, f)
         p = tmp_path / "sq.obj"
@@ -98,6 +98,18 @@ def test_obj_text_of_a_hand_derived_case(tmp_path):
                 f"v 0.00000000 0.00000000 {zt}{COL}", f"v 0.50000000 0.00000000 {zt}{COL}",
                 f"v 0.00000000 0.50000000 {zt}{COL}", f"v 0.50000000 0.50000000 {zt}{COL}"] + faces_txt
         assert p.read_text().splitlines() == want
+
+
+def test_open_patch_is_oriented_by_the_volume_integral_not_by_tetrahedra():
+    """An open patch in the plane x = c (normal along +x or -x): integral term = cross_x * (x0 + x1 + x2) = (+-2 A) * 3 c.  With the
+    normal along +x and c < 0 the integral is negative -> the patch is reversed; at c > 0 it stays.  (Hand-derived: two triangles of
+    area 1/8 each, cross_x = +1/4, sum x = 3 c -> 6 V = 2 * 3 c / 4.)"""
+    for c, flipped in ((0.25, False), (-0.25, True)):
+        coords = np.array([[[c, 0, 0], [c, 0.5, 0], [c, 0, 0.5]], [[c, 0.5, 0], [c, 0.5, 0.5], [c, 0, 0.5]]], np.float32)
+        v, f = faces_from_coords(coords)
+        assert f.tolist() == [[0, 1, 2], [1, 3, 2]]
+        got = fix_normals(v, f)
+        assert got.tolist() == ([[2, 1, 0], [2, 3, 1]] if flipped else [[0, 1, 2], [1, 3, 2]])
 
 
 def test_vertices_keep_first_occurrence_order_not_sorted_order():
@@ -116,16 +128,17 @@ def test_degenerate_faces_stay_and_never_pair_with_themselves():
 
 def test_one_group_plus_a_loose_face_is_oriented_as_a_whole():
     """Vertex graph with two components (body_count 2 -> multibody) but ONE face-adjacency group: fix_inversion's single-group
-    escape reverses the whole mesh by its total volume -- the loose triangle included."""
+    escape reverses the whole mesh by its total volume -- the loose triangle included.  The loose triangle lies in a plane z = const, so
+    its term of trimesh's volume integral is cross_x * sum(x) = 0: the tetrahedron's sign alone decides."""
     v1 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
     good = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
     v = np.concatenate([v1, np.array([[5, 5, 5], [6, 5, 5], [5, 6, 5]], np.float32)])
-    loose = np.array([[4, 5, 6]])                            # 6 V = v0 . (v1 x v2) = +5
-    fixed = fix_normals(v, np.concatenate([good[:, ::-1], loose]))          # total 6 V = -1 + 5 > 0: nothing reversed, the body stays inverted
-    assert np.array_equal(fixed, np.concatenate([good[:, ::-1], loose]))
-    loose_neg = loose[:, ::-1]                               # 6 V = -5: total -6 < 0 -> every face reversed
-    fixed = fix_normals(v, np.concatenate([good[:, ::-1], loose_neg]))
-    assert np.array_equal(fixed, np.concatenate([good, loose]))
+    loose = np.array([[4, 5, 6]])                            # cross = (0, 0, 1): contributes 0 whichever way it is wound
+    for lf in (loose, loose[:, ::-1]):
+        fixed = fix_normals(v, np.concatenate([good[:, ::-1], lf]))             # inverted tetrahedron: 6 V = -1 < 0 -> every face reversed
+        assert np.array_equal(fixed, np.concatenate([good, lf[:, ::-1]]))
+        fixed = fix_normals(v, np.concatenate([good, lf]))                      # 6 V = +1: nothing reversed
+        assert np.array_equal(fixed, np.concatenate([good, lf]))
 
 
 def test_bodies_that_touch_in_one_vertex_count_as_one_body():
