@@ -288,7 +288,7 @@ MA_API int  ma_op_set_half_dtype(int dtype);
  * reports the box's achievable HBM rate next to the 8 TB/s vendor number.  No reference counterpart. */
 MA_API int  ma_op_stream_copy(void *dst, const void *src, size_t bytes, int mode, void *stream);
 
-/* ---- persistent decode step (csrc/persist.hpp; only in libraries built with MA_EXPERIMENTAL=1 -- measured 1.3-1.6x slower than the launch
+/* ---- persistent decode step (csrc/experimental/persist.hpp; only in libraries built with MA_EXPERIMENTAL=1 -- measured 1.3-1.6x slower than the launch
  * chain; the product build answers MA_ERR_STATE / 0): the whole batch-1 greedy step as ONE resident launch instead of the
  * 123-launch chain.  Select with ma_engine_set_option(e, "decode_impl", 1); it is used when ma_engine_persist_available()
  * and the call is batch 1 / greedy, otherwise the chain runs.  replaces: the same reference calls as ma_generate's steps

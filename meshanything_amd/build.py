@@ -23,7 +23,7 @@ HEADER = os.path.normpath(os.path.join(HERE, "..", "include", "meshanything_amd.
 # MA_DEBUG=1 selects the debug variant ("race detection / sanitizers"): -O1 -g, device-side assert()s alive
 # (the release build defines NDEBUG), its own file name so the two never shadow each other; `_lib.load()` follows the same variable.
 # MA_DEBUG=asan additionally asks for HIP AddressSanitizer (host + device instrumentation; needs an xnack+ capable setup).
-# MA_EXPERIMENTAL=1 compiles the measured-and-rejected decode-step forms in as well (persist.hpp, rows_fused.hpp, layer_fused.hpp,
+# MA_EXPERIMENTAL=1 compiles the measured-and-rejected decode-step forms in as well (csrc/experimental/: persist.hpp, rows_fused.hpp, layer_fused.hpp,
 # the dense GEMM's A/B variants); the product build leaves them out.  Its own file name, like the debug variant.
 EXPERIMENTAL = os.environ.get("MA_EXPERIMENTAL", "") not in ("", "0")
 DEBUG = os.environ.get("MA_DEBUG", "") not in ("", "0")
@@ -42,7 +42,9 @@ if EXPERIMENTAL:
 
 
 def source_files():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))) + [HEADER]
+    # csrc/experimental/: the measured-and-rejected decode-step forms (compiled only with MA_EXPERIMENTAL=1, but always part of the hash: one
+    # rule for both library variants)
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "experimental", "*.hpp"))) + [HEADER]
 
 
 def have_sources() -> bool:

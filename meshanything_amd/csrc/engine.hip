@@ -33,14 +33,15 @@
 #include "oproj_fc1.hpp"
 #include "qkv_attn.hpp"
 #include "rows_attn.hpp"
+#include "rows_mlp.hpp"
 #include "state.hpp"
 // MA_EXPERIMENTAL (build.py: MA_EXPERIMENTAL=1): the measured-and-rejected decode-step forms -- the persistent one-launch step
 // (persist.hpp), the rows-looped two-launch layer (rows_fused.hpp) and the layer-pair launch (layer_fused.hpp); DESIGN.md records why
 // each lost.  They are evidence, not product: the shipped library does not contain them, their tests skip without the flag.
 #ifdef MA_EXPERIMENTAL
-#include "persist.hpp"
-#include "rows_fused.hpp"
-#include "layer_fused.hpp"
+#include "experimental/persist.hpp"
+#include "experimental/rows_fused.hpp"
+#include "experimental/layer_fused.hpp"
 #endif
 #include "weights.hpp"
 
@@ -194,6 +195,8 @@ struct ma_engine {
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
+    int opt_rows_attn_early = 1;     // rows_attn.hpp: the first cache round requested in the kernel's first instructions (A/B)
+    int opt_fuse_rows_mlp = 1;       // ... and LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp; its relu(fc1) exchange uses d_ffn_gran)
     u64 *d_ra_qkv_gran = nullptr, *d_ra_out_gran = nullptr;      // its exchanges: [max_batch][RA_QKV_GRANULES], [max_batch][RA_OUT_GRANULES]
     u64* d_y2_gran = nullptr;        // [max_batch][hidden] granules (y2 handed to the next layer inside a launch)
     u64* d_ffn_gran = nullptr;       // [max_batch][ffn] granules (fc2 in the out_proj + fc1 launch)
@@ -517,7 +520,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
                 a.qkv_gran = e->d_ra_qkv_gran + r0 * RA_QKV_GRANULES; a.pair_gran = e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES; a.out_gran = e->d_ra_out_gran + r0 * RA_OUT_GRANULES;
                 a.err = e->d_chain_err; a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.y1 = y1; a.y1_stride = H;
                 a.trace = tm.trace_slot(2, 256);
-                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_attn<HT>(a, c.heads, B, s));
+                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_attn<HT>(a, c.heads, B, s, e->opt_rows_attn_early != 0));
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_attn launch failed: ") + hipGetErrorString(r));
             }
         } else {
@@ -558,6 +561,21 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         }
         ProIn in1;
         if (ks_o_eff > 1 && !fused_attn) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
+        // 8 rows: LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp): the same gates as the fused first half, and y1 complete in one buffer
+        const bool fused_mlp = e->opt_fuse_rows_mlp && pair_ok && B == RA_ROWS && len_override < 0 && H == 1024 && c.ffn == 4096 && fold1 && ks_f == 4 && in1.nparts == 1 &&
+                               (size_t)c.ffn >= (size_t)RM_FFN_GRANULES;
+        if (fused_mlp) {
+            if (tm.on(0)) {
+                RowsMlpArgs a{};
+                a.y1 = in1.x; a.y1_stride = H; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.h1_out = h1; a.h1_stride = H;
+                a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b; a.W2 = reinterpret_cast<const bf16_t*>(w.fc2_w); a.part = partF; a.part_stride = H;
+                a.st = e->d_st + r0; a.layer = l; a.ffn_gran = e->d_ffn_gran + r0 * c.ffn; a.err = e->d_chain_err;
+                a.trace = tm.trace_slot(4, 256);
+                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_mlp<HT>(a, B, H, c.ffn, s));
+                if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_mlp launch failed: ") + hipGetErrorString(r));
+            }
+            continue;
+        }
         if (!fold1) rows_prologue(e, s, PRO_LN, rw, in1, w.ln1_g, w.ln1_b, h1, tm);
         {
             GemmDecArgs a{};
@@ -1464,6 +1482,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         }
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "fuse_rows_attn") { e->opt_fuse_rows_attn = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "fuse_rows_mlp") { e->opt_fuse_rows_mlp = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "rows_attn_early") { e->opt_rows_attn_early = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
@@ -1548,6 +1568,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
         else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn;
+        else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp;
+        else if (n == "rows_attn_early") *value = e->opt_rows_attn_early;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;

@@ -47,7 +47,7 @@ template <int N> __device__ __forceinline__ void g256_wait_vm() { asm volatile("
 // ACT: the activation is a template parameter here (128 accumulators x an inlined erf would otherwise sit in every instantiation)
 // ABL (scripts/ubench_gemm256.hip only; 0 in the library): ablation bits -- 1 no LDS-DMA in the loop, 2 no ds_reads, 4 no MFMAs, 8 no stores
 template <typename HT, int ACT, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
+MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char g256_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
     // XCD-aware hand-out: workgroups go to the XCDs round-robin; XCD i works on the i-th eighth of this launch's tile range

@@ -40,10 +40,14 @@ struct GemmTArgs {
     int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
 };
 
-__device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
+// MA_NO_ASAN: the LDS-DMA kernels stay uninstrumented in the sanitizer build (MA_DEBUG=asan): device ASan lowers a kernel's LDS to global
+// memory, where a `global_load ... lds` has no destination (hipcc then fails on the M0 operand of this statement)
+#define MA_NO_ASAN __attribute__((no_sanitize("address")))
+MA_NO_ASAN __device__ __forceinline__ void gt_glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");      // (wave-uniform by contract; the
+                                                                                                                 //  explicit readfirstlane keeps it in an SGPR in unoptimised / sanitizer builds too)
 }
 
 template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -59,7 +63,7 @@ template <int N> __device__ __forceinline__ void gt_wait_vm() { asm volatile("s_
 // third less LDS fill per FLOP than 128 x 128 (the loop is bound by the LDS-DMA issue and fill rate, not by the matrix cores).
 // HT: the 16-bit format of both operands and of the 16-bit output (bf16_t | f16_t, common.hpp H16)
 template <typename HT, int BM, int BN, int BK, int NS, bool RAW = false, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
+MA_NO_ASAN __global__ __launch_bounds__(WM * WN * 64) void gemm_tile_kernel(GemmTArgs g) {
     constexpr int NW = WM * WN;
     constexpr int CH = BK / 8;                        // 16-byte chunks per tile row
     auto swz = [](int r) { return CH == 8 ? (r & 7) : ((r >> 1) & 3); };

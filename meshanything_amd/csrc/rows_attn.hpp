@@ -56,7 +56,9 @@ struct RowsAttnArgs {
 };
 
 // HASLN: the rows are LayerNorm(sum of PARTS partial buffers [+ pbias + pres when DEFER]); otherwise they come as 16-bit from `xb`
-template <bool HASLN, int PARTS, bool DEFER, typename HT>
+// EARLY: the first cache round is requested in the kernel's first instructions (true) or only once the row's vectors have arrived (false):
+// A/B switch, engine option rows_attn_early
+template <bool HASLN, int PARTS, bool DEFER, bool EARLY, typename HT>
 __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     using G = AttnGeom<HT>;
     constexpr int K = 1024, NW = 8, KW = K / NW, CH = KW / 32, XS = K + 16;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) vr[u] = ld_stream16(vh + (size_t)min(base + u * PPW, a.max_seq - 1) * 64);
     };
-    early(0, kA, vA);
+    if constexpr (EARLY) early(0, kA, vA);
     asm volatile("" ::: "memory");
     // (a memory clobber orders requests, not arithmetic: hipcc hoists the sums of step B above the weight / cache requests and waits for the row
     //  in front of them.  Passing the row's registers through an empty asm HERE pins their first use behind every request above.)
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
                 s[i].x += va[i].x; s[i].y += va[i].y; s[i].z += va[i].z; s[i].w += va[i].w;
             }
         }
-        early(1, kB, vB);                                   // (the row's vectors have collapsed: registers for the second round)
+        if constexpr (EARLY) early(1, kB, vB);              // (the row's vectors have collapsed: registers for the second round)
+        else early(0, kA, vA);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(s[i]));
@@ -174,7 +177,9 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             *reinterpret_cast<u32x2*>(&xl[w * XS + idx]) = pack4<HT>(s[i]);
             if (idx >= n0 && idx < n0 + 16) *reinterpret_cast<f32x4*>(&resl[w][idx - n0]) = s[i];
         }
+        if constexpr (!EARLY) early(1, kB, vB);
     } else {
+        if constexpr (!EARLY) early(0, kA, vA);
         early(1, kB, vB);
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -401,24 +406,29 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
         v.x += ob.x; v.y += ob.y; v.z += ob.z; v.w += ob.w;        // gd_epi_store: + bias, then + residual
         v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
         *reinterpret_cast<f32x4*>(a.y1 + (size_t)m * a.y1_stride + n0 + kg * 4) = v;
+        if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();       // (the out_proj blocks: their end, not their hand-over)
     }
 }
 
 template <typename HT>
-inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s) {
+inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s, bool early_kv = true) {
     if (heads != 16 || rows != RA_ROWS || !a.Wqkv || !a.Wo || !a.qkv_gran || !a.pair_gran || !a.out_gran || !a.err || !a.y1 || a.y1_stride % 4) return hipErrorInvalidValue;
     const dim3 grid(16, RA_ROWS, 2), block(512);
     if (!a.ln_g) {
         if (!a.xb || !a.res || a.xb_stride % 8 || a.res_stride % 4) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((rows_attn_kernel<false, 1, false, HT>), grid, block, 0, s, a);
+        if (early_kv) hipLaunchKernelGGL((rows_attn_kernel<false, 1, false, true, HT>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((rows_attn_kernel<false, 1, false, false, HT>), grid, block, 0, s, a);
         return hipGetLastError();
     }
     if (!a.pin || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) || (a.pbias != nullptr) != (a.pres != nullptr)) return hipErrorInvalidValue;
     const bool d = a.pres != nullptr;
-    if (a.pin_parts == 1 && !d) hipLaunchKernelGGL((rows_attn_kernel<true, 1, false, HT>), grid, block, 0, s, a);
-    else if (a.pin_parts == 2 && d) hipLaunchKernelGGL((rows_attn_kernel<true, 2, true, HT>), grid, block, 0, s, a);
-    else if (a.pin_parts == 4 && d) hipLaunchKernelGGL((rows_attn_kernel<true, 4, true, HT>), grid, block, 0, s, a);
+#define MA_RA(P, D) do { if (early_kv) hipLaunchKernelGGL((rows_attn_kernel<true, P, D, true, HT>), grid, block, 0, s, a); \
+                         else hipLaunchKernelGGL((rows_attn_kernel<true, P, D, false, HT>), grid, block, 0, s, a); } while (0)
+    if (a.pin_parts == 1 && !d) MA_RA(1, false);
+    else if (a.pin_parts == 2 && d) MA_RA(2, true);
+    else if (a.pin_parts == 4 && d) MA_RA(4, true);
     else return hipErrorInvalidValue;
+#undef MA_RA
     return hipGetLastError();
 }
 

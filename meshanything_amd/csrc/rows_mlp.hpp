@@ -1,0 +1,186 @@
+// The second half of a decoder layer for EIGHT rows stepping together, in ONE launch: LayerNorm 1 (folded prologue) -> fc1 + bias + ReLU on
+// the matrix cores -> fc2 (split along K over four blocks per 16-row tile; raw partial sums, whose bias / residual / LayerNorm 2 run in the
+// next layer's prologue).  Replaces two launches of the batched matrix-core chain (gemm_dec_ln_kernel<1, false, 8> | gemm_dec_kernel<1, 8>
+// with ksplit 4; [3p] OPTDecoderLayer fc1 / activation_fn / fc2 reached from shape_opt.py:403-410).  The seam between them is an all-gather
+// of relu(fc1): 8 rows x 4096 16-bit values -- but a K-split fc2 block needs only its quarter, 16 KB (scripts/ubench_allgather.hip prices
+// that gather against the launch boundary it replaces: profiles/r05_ubench_allgather.txt).
+//
+// grid 256 blocks of 8 waves, one per CU (all resident: the gate, bounded sweeps and fall-back of the other fused launches).  Block i:
+//   A. requests: LayerNorm parameters, row `wave` of y1, its fc1 tile (rows 16 i .. 16 i + 15, the 8 waves split K = 1024), then its fc2 tile
+//      (rows 16 (i >> 2) .., K quarter i & 3: 32 KB, requested once the row has collapsed) -- both weight streams are under way before the
+//      first LayerNorm instruction;
+//   B. normalises the eight rows (one per wave), parks them in LDS as 16-bit; block 0 writes the fp32 rows (h1: the residual the next
+//      layer's prologue adds);
+//   C. fc1 MFMAs, the waves meet in LDS (gemm_dec_ln_kernel's order), wave 0 adds bias, ReLU, rounds and publishes 16 values per row as
+//      {epoch, two 16-bit values} granules;
+//   D. every wave sweeps one row's 512 granules of the block's K quarter into LDS; four waves run gemm_dec_kernel<1, 8>'s K split of the
+//      fc2 tile; wave 0 stores the raw partial sums [quarter][row][1024] -- the bits the two-launch form produces.
+// Epoch = position * 32 + layer + 1, as in rows_attn.hpp (its own buffer).  HBM-bound: 16 MB of fc1 + fc2 weights per launch.
+#pragma once
+#include "common.hpp"
+#include "gemm_decode.hpp"
+#include "rows_attn.hpp"
+#include "state.hpp"
+
+namespace ma {
+
+constexpr unsigned RM_ERR_FFN = 1024;
+constexpr int RM_FFN_GRANULES = 4096 / 2;                  // per row: relu(fc1) as pairs
+
+struct RowsMlpArgs {
+    const float* y1; int y1_stride;                        // [8][1024] fp32: residual + out_proj (rows_attn.hpp)
+    const float* ln_g; const float* ln_b; float ln_eps;    // LayerNorm 1
+    float* h1_out; int h1_stride;                          // its fp32 output (the residual of fc2, added by the next layer's prologue)
+    const bf16_t* W1; const float* b1;                     // fc1 [4096][1024], [4096]
+    const bf16_t* W2;                                      // fc2 [1024][4096]
+    float* part; int part_stride;                          // out: raw fc2 partial sums [4][8][part_stride]
+    const DecState* st; int layer;
+    u64* ffn_gran;                                         // [8][RM_FFN_GRANULES]
+    unsigned* err;
+    unsigned long long* trace;
+};
+
+template <typename HT>
+__global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
+    constexpr int K = 1024, F = 4096, NW = 8, KW = K / NW, CH = KW / 32, XS = K + 16;
+    __shared__ __attribute__((aligned(16))) bf16_t xl[RA_ROWS * XS];       // LayerNorm output as 16-bit (step C); later the block's quarter of relu(fc1) (step D)
+    __shared__ __attribute__((aligned(16))) float red[NW][64][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, kg = lane >> 4;
+    const int i = blockIdx.x;
+    const int n1 = i * 16;                                  // fc1 rows of this block
+    const int t2 = i >> 2, kq = i & 3, n2 = t2 * 16;        // fc2 tile and K quarter
+    const unsigned epoch = (unsigned)a.st[0].pos * 32u + (unsigned)a.layer + 1u;       // (rows step together: one position; read before any store: a scalar load)
+    unsigned long long* tr = a.trace ? a.trace + (size_t)i * 4 : nullptr;
+    if (tr && threadIdx.x == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- A: requests ------------------------------------------------------------------------------------------------------------------
+    f32x4 gv[4], bv[4], s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int idx = (lane + 64 * c) * 4;
+        gv[c] = *reinterpret_cast<const f32x4*>(a.ln_g + idx);
+        bv[c] = *reinterpret_cast<const f32x4*>(a.ln_b + idx);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = *reinterpret_cast<const f32x4*>(a.y1 + (size_t)w * a.y1_stride + (lane + 64 * c) * 4);
+    asm volatile("" ::: "memory");
+    const int kbase = w * KW + kg * 8;
+    const bf16_t* w1row = a.W1 + (size_t)(n1 + m) * K + kbase;
+    u32x4 wv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) wv[c] = ld_stream16(w1row + c * 32);
+    const f32x4 fb = *reinterpret_cast<const f32x4*>(a.b1 + n1 + kg * 4);
+    // fc2 tile: rows n2 + m, the K split of gemm_dec_kernel<1, 8> with ksplit 4 (four waves x 256 inside the quarter; waves 4 .. 7 shadow 0 .. 3)
+    const bf16_t* w2row = a.W2 + (size_t)(n2 + m) * F + kq * 1024 + (w & 3) * 256 + kg * 8;
+    u32x4 w2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w2[c] = ld_stream16(w2row + c * 32);
+    asm volatile("" ::: "memory");
+    // (pin the row's first use behind every request above: rows_attn.hpp, step A)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(s[c]));
+
+    // ---- B: LayerNorm 1 of row `w` (gemm_dec_ln_kernel::norm_row) -----------------------------------------------------------------------
+    {
+        const float x0 = readlane_f(s[0].x, 0);
+        float sm1 = 0.f, sq1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ln_chunk_moments(s[c], x0, sm1, sq1);
+        sm1 = wave_sum(sm1); sq1 = wave_sum(sq1);
+        float md, rstd;
+        ln_finish(sm1, 0.f, 0.f, 0.f, sq1, 0.f, 0.f, 0.f, K, a.ln_eps, md, rstd);
+        const bool writer = a.h1_out && i == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = (lane + 64 * c) * 4;
+            ln_apply(s[c], md, rstd, gv[c], bv[c]);
+            if (writer) *reinterpret_cast<f32x4*>(a.h1_out + (size_t)w * a.h1_stride + idx) = s[c];
+            *reinterpret_cast<u32x2*>(&xl[w * XS + idx]) = pack4<HT>(s[c]);
+        }
+    }
+    __syncthreads();
+
+    // ---- C: fc1 tile for all eight rows -------------------------------------------------------------------------------------------------
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xr = xl + min(m, RA_ROWS - 1) * XS + kbase;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc = H16<HT>::mfma16(wv[c], *reinterpret_cast<const u32x4*>(xr + c * 32), acc);
+        *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
+    }
+    __syncthreads();
+    if (w == 0 && m < RA_ROWS) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
+#pragma unroll
+        for (int c = 1; c < NW; ++c) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(&red[c][lane][0]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        v.x = fmaxf(v.x + fb.x, 0.f); v.y = fmaxf(v.y + fb.y, 0.f); v.z = fmaxf(v.z + fb.z, 0.f); v.w = fmaxf(v.w + fb.w, 0.f);
+        // lane (m, kg): row m, fc1 outputs n1 + 4 kg .. + 3
+        u64* g = a.ffn_gran + (size_t)m * RM_FFN_GRANULES + (n1 + 4 * kg) / 2;
+        ps_publish(g, 0, epoch, H16<HT>::pack2(v.x, v.y));
+        ps_publish(g, 1, epoch, H16<HT>::pack2(v.z, v.w));
+    }
+    if (tr && threadIdx.x == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();                                        // (xl: every wave is past its step-C reads)
+
+    // ---- D: the K quarter of relu(fc1), row `w`: 512 granules; then the fc2 tile ----------------------------------------------------------
+    {
+        const gu64* ga = (const gu64*)(a.ffn_gran + (size_t)w * RM_FFN_GRANULES + kq * 512);
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        u64 v[8];
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                v[c] = __hip_atomic_load(ga + lane + 64 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (unsigned)(v[c] >> 32) == epoch;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (xchg_expired(spins, t0, a.err)) {
+                if (lane == 0) xchg_raise(a.err, RM_ERR_FFN);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = 0;
+                break;
+            }
+        }
+        if (lane == 0) xchg_note_slow(a.err, spins, t0);
+        unsigned* al = reinterpret_cast<unsigned*>(xl + w * XS);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) al[lane + 64 * c] = (unsigned)v[c];
+    }
+    __syncthreads();
+    if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xr = xl + min(m, RA_ROWS - 1) * XS + (w & 3) * 256 + kg * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc = H16<HT>::mfma16(w2[c], *reinterpret_cast<const u32x4*>(xr + c * 32), acc);
+        *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
+    }
+    __syncthreads();
+    if (w == 0 && m < RA_ROWS) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(&red[c][lane][0]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *reinterpret_cast<f32x4*>(a.part + ((size_t)kq * RA_ROWS + m) * a.part_stride + n2 + kg * 4) = v;      // raw partial sums (gd_epi_store, ksplit > 1)
+        if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template <typename HT>
+inline hipError_t launch_rows_mlp(const RowsMlpArgs& a, int rows, int hidden, int ffn, hipStream_t s) {
+    if (rows != RA_ROWS || hidden != 1024 || ffn != 4096 || !a.y1 || !a.ln_g || !a.ln_b || !a.W1 || !a.b1 || !a.W2 || !a.part || !a.st || !a.ffn_gran || !a.err ||
+        a.y1_stride % 4 || a.part_stride % 4 || (a.h1_out && a.h1_stride % 4)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((rows_mlp_kernel<HT>), dim3(256), dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ma

@@ -271,7 +271,7 @@ class Engine:
         return {"coords": coords, "tokens": tokens[:, :ngen.value], "lengths": np.array(list(lengths), dtype=np.int32),
                 "ids": ids, "latents": latents}
 
-    # ---------------------------------------------------------------- persistent decode step (csrc/persist.hpp)
+    # ---------------------------------------------------------------- persistent decode step (csrc/experimental/persist.hpp)
     def persist_available(self) -> bool:
         """True when `set_option("decode_impl", 1)` can take effect: bf16, 350M layer shape, 256-CU device."""
         return bool(self.lib.ma_engine_persist_available(self.h))

@@ -1,4 +1,4 @@
-"""The persistent decode step (csrc/persist.hpp: one resident launch per step) against the launch chain it replaces, at the
+"""The persistent decode step (csrc/experimental/persist.hpp: one resident launch per step) against the launch chain it replaces, at the
 BASELINE.json configs[1] shape (350M, bf16, batch 1, greedy): the two implementations run the same arithmetic in the same
 order, so the test demands bit-identical logits and token-identical streams, not a tolerance."""
 import os
@@ -266,7 +266,7 @@ def test_fc2_inside_the_oproj_fc1_launch_is_bitwise(eng):
 
 @pytest.mark.gpu
 def test_layer_pair_launch_is_bitwise(eng):
-    """fuse_layer: the second half of layer l and the first half of layer l + 1 in one launch (csrc/layer_fused.hpp; y2 all-gathered
+    """fuse_layer: the second half of layer l and the first half of layer l + 1 in one launch (csrc/experimental/layer_fused.hpp; y2 all-gathered
     inside it).  Same device functions as the two launches it replaces: bit-identical logits and tokens, batch 1 and 2 rows."""
     if not eng.get_option("experimental"):
         pytest.skip("the layer-pair launch is not part of the product build (MA_EXPERIMENTAL=1)")

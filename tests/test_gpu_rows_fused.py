@@ -1,4 +1,4 @@
-"""The rows-looped two-launch decoder layer for batches of 2 .. 8 rows (csrc/rows_fused.hpp, option rows_fused = 1; NOT the default: it is
+"""The rows-looped two-launch decoder layer for batches of 2 .. 8 rows (csrc/experimental/rows_fused.hpp, option rows_fused = 1; NOT the default: it is
 bit-identical to batch-1 runs and needs 51 launches per step instead of 125, but the per-row work serialised inside each block makes it
 1.4-1.9x slower than the matrix-core launch chain -- profiles/r03_rows_fused_*.txt) at the 350M shape: every block keeps its
 weight rows in registers and loops over the batch rows, the in-launch all-gathers carry all rows at once, and the arithmetic per row
