@@ -195,7 +195,9 @@ struct ma_engine {
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
-    int opt_rows_attn_early = 1;     // rows_attn.hpp: the first cache round requested in the kernel's first instructions (A/B)
+    int opt_rows_attn_early = 3;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 3 = one round behind the q/k/v MFMAs, not by the sweeping wave
+    int opt_rows_mlp_ln2 = 1;        // rows_mlp.hpp step E: LayerNorm 2 finished in the MLP launch (the next q/k/v starts from 16-bit rows)
+    u64* d_rm_y2_gran = nullptr;     // its exchange: [max_batch][RM_Y2_GRANULES]
     int opt_fuse_rows_mlp = 1;       // ... and LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp; its relu(fc1) exchange uses d_ffn_gran)
     u64 *d_ra_qkv_gran = nullptr, *d_ra_out_gran = nullptr;      // its exchanges: [max_batch][RA_QKV_GRANULES], [max_batch][RA_OUT_GRANULES]
     u64* d_y2_gran = nullptr;        // [max_batch][hidden] granules (y2 handed to the next layer inside a launch)
@@ -486,12 +488,15 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     const bool fold1 = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_fc1_max && B <= 16 && H == 1024;      // LN1 inside fc1
     const bool fold = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_qkv_max && B <= 16 && H == 1024;       // LN2 inside q/k/v
     const int ks_o_eff = fold1 ? 1 : ks_o;
+    bool ln2_prev = false;                                      // the previous layer's MLP launch finished its LayerNorm 2 (rows_mlp.hpp step E): xb and h0 are ready
     for (int l = 0; l < L; ++l) {
         const DecLayerPtrs& w = e->dl[l];
         const float* resid;
         ProIn qin;                                              // input of this layer's q/k/v GEMM when its LayerNorm is folded
         if (l == 0) {
             resid = x_embed;                                    // (its 16-bit copy xb was written by the embedding launch)
+        } else if (ln2_prev) {
+            resid = h0;
         } else {
             ProIn in;
             if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[l - 1].fc2_b; in.res = h1; } else in.x = y2;
@@ -505,12 +510,12 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         // 8 rows: LayerNorm 2 + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp) -- three launches per layer instead of five.  Its
         // exchange epochs come from DecState.pos (no caller-supplied length), its 256 blocks of 8 waves need every CU (pair_ok's gate)
         const bool fused_attn = e->opt_fuse_rows_attn && pair_ok && B == RA_ROWS && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && len_override < 0 &&
-                                H == 1024 && c.heads == 16 && fold;
+                                H == 1024 && c.heads == 16 && (fold || ln2_prev);
         if (fused_attn) {
             if (tm.on(1)) {
                 RowsAttnArgs a{};
                 a.Wqkv = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bqkv = w.qkv_b;
-                if (l == 0) { a.xb = xb; a.xb_stride = H; a.res = x_embed; a.res_stride = H; }
+                if (l == 0 || ln2_prev) { a.xb = xb; a.xb_stride = H; a.res = resid; a.res_stride = H; }
                 else {
                     a.pin = qin.x; a.pin_stride = H; a.pin_parts = qin.nparts; a.pbias = qin.bias; a.pres = qin.res; a.pres_stride = H;
                     a.ln_g = e->dl[l - 1].ln2_g; a.ln_b = e->dl[l - 1].ln2_b; a.ln_eps = 1e-5f; a.xn_out = h0; a.xn_stride = H;
@@ -520,7 +525,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
                 a.qkv_gran = e->d_ra_qkv_gran + r0 * RA_QKV_GRANULES; a.pair_gran = e->d_attn_pair_gran + r0 * c.heads * ATTN_PAIR_GRANULES; a.out_gran = e->d_ra_out_gran + r0 * RA_OUT_GRANULES;
                 a.err = e->d_chain_err; a.Wo = reinterpret_cast<const bf16_t*>(w.o_w); a.bo = w.o_b; a.y1 = y1; a.y1_stride = H;
                 a.trace = tm.trace_slot(2, 256);
-                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_attn<HT>(a, c.heads, B, s, e->opt_rows_attn_early != 0));
+                hipError_t r = H16_CALL(e->hdt, HT, launch_rows_attn<HT>(a, c.heads, B, s, e->opt_rows_attn_early, l == 0 ? 4 : 8));
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_attn launch failed: ") + hipGetErrorString(r));
             }
         } else {
@@ -528,7 +533,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             GemmDecArgs a{};
             a.W = reinterpret_cast<const bf16_t*>(w.qkv_w); a.bias = w.qkv_b; a.xb = xb; a.xb_stride = H; a.y = q; a.y_stride = H; a.N = 3 * H; a.K = H; a.B = B; a.ksplit = 1;
             a.epi = EPI_QKV; a.kcache = e->kplane(rw.r0, l); a.vcache = e->vplane(rw.r0, l); a.kv_row_stride = kv_row_elems; a.H = H; a.max_seq = e->maxseq; a.st = e->d_st + r0;
-            if (fold && l > 0) {
+            if (fold && l > 0 && !ln2_prev) {
                 a.pin = qin.x; a.pin_stride = H; a.pin_parts = qin.nparts; a.pbias = qin.bias; a.pres = qin.res; a.pres_stride = H;
                 a.ln_g = e->dl[l - 1].ln2_g; a.ln_b = e->dl[l - 1].ln2_b; a.ln_eps = 1e-5f; a.xn_out = h0; a.xn_stride = H;
                 gemm_dec_ln(e, s, a, tm, 1);
@@ -570,12 +575,20 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
                 a.y1 = in1.x; a.y1_stride = H; a.ln_g = w.ln1_g; a.ln_b = w.ln1_b; a.ln_eps = 1e-5f; a.h1_out = h1; a.h1_stride = H;
                 a.W1 = reinterpret_cast<const bf16_t*>(w.fc1_w); a.b1 = w.fc1_b; a.W2 = reinterpret_cast<const bf16_t*>(w.fc2_w); a.part = partF; a.part_stride = H;
                 a.st = e->d_st + r0; a.layer = l; a.ffn_gran = e->d_ffn_gran + r0 * c.ffn; a.err = e->d_chain_err;
+                // LayerNorm 2 in this launch's tail: the next layer starts from 16-bit rows.  Not for the last layer: the rows that feed lm_head are
+                // normalised by rows_prologue_kernel (block-level sums: another order than the one-wave LayerNorm of the folded GEMMs)
+                if (e->opt_rows_mlp_ln2 && l + 1 < L) {
+                    a.b2 = w.fc2_b; a.ln2_g = w.ln2_g; a.ln2_b = w.ln2_b; a.y2_gran = e->d_rm_y2_gran + r0 * RM_Y2_GRANULES;
+                    a.x2_out = h0; a.x2_stride = H; a.xb_out = xb; a.xb_stride = H; a.part = nullptr;
+                }
                 a.trace = tm.trace_slot(4, 256);
                 hipError_t r = H16_CALL(e->hdt, HT, launch_rows_mlp<HT>(a, B, H, c.ffn, s));
                 if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("rows_mlp launch failed: ") + hipGetErrorString(r));
             }
+            ln2_prev = e->opt_rows_mlp_ln2 != 0 && l + 1 < L;
             continue;
         }
+        ln2_prev = false;
         if (!fold1) rows_prologue(e, s, PRO_LN, rw, in1, w.ln1_g, w.ln1_b, h1, tm);
         {
             GemmDecArgs a{};
@@ -597,7 +610,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     // lm_head on LN2_{L-1}(y2)
     ProIn in;
     if (ks_f > 1) { in.x = partF; in.nparts = ks_f; in.bias = e->dl[L - 1].fc2_b; in.res = h1; } else in.x = y2;
-    rows_prologue(e, s, PRO_LN, rw, in, e->dl[L - 1].ln2_g, e->dl[L - 1].ln2_b, nullptr, tm);
+    if (!ln2_prev) rows_prologue(e, s, PRO_LN, rw, in, e->dl[L - 1].ln2_g, e->dl[L - 1].ln2_b, nullptr, tm);      // (else: the last MLP launch left xb)
     GemmDecArgs g{};
     g.W = reinterpret_cast<const bf16_t*>(e->P("transformer.lm_head.weight")); g.xb = xb; g.xb_stride = H;
     g.y = e->d_logits + r0 * e->V; g.y_stride = e->V; g.N = e->V; g.K = H; g.B = B; g.ksplit = 1;
@@ -1059,6 +1072,7 @@ void init_state(ma_engine* e, hipStream_t s, const ma_sample_cfg& sc, int B, int
     HIP_CHECK(hipMemsetAsync(e->d_y2_gran, 0, (size_t)e->cfg.max_batch * e->cfg.hidden * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_ra_qkv_gran, 0, (size_t)e->cfg.max_batch * RA_QKV_GRANULES * sizeof(u64), s));
     HIP_CHECK(hipMemsetAsync(e->d_ra_out_gran, 0, (size_t)e->cfg.max_batch * RA_OUT_GRANULES * sizeof(u64), s));
+    HIP_CHECK(hipMemsetAsync(e->d_rm_y2_gran, 0, (size_t)e->cfg.max_batch * RM_Y2_GRANULES * sizeof(u64), s));
 #ifdef MA_EXPERIMENTAL
     HIP_CHECK(hipMemsetAsync(e->d_part_gran, 0, (size_t)e->cfg.max_batch * e->cfg.heads * ATTN_NCHUNK * RF_PART * sizeof(u64), s));
 #endif
@@ -1275,6 +1289,8 @@ void build_engine(ma_engine* e) {
     e->d_ra_qkv_gran = e->dmalloc<u64>(MB * RA_QKV_GRANULES); e->d_ra_out_gran = e->dmalloc<u64>(MB * RA_OUT_GRANULES);
     HIP_CHECK(hipMemset(e->d_ra_qkv_gran, 0, MB * RA_QKV_GRANULES * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_ra_out_gran, 0, MB * RA_OUT_GRANULES * sizeof(u64)));
+    e->d_rm_y2_gran = e->dmalloc<u64>(MB * RM_Y2_GRANULES);
+    HIP_CHECK(hipMemset(e->d_rm_y2_gran, 0, MB * RM_Y2_GRANULES * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
     HIP_CHECK(hipMemset(e->d_ffn_gran, 0, MB * (size_t)c.ffn * sizeof(u64)));
 #ifdef MA_EXPERIMENTAL
@@ -1483,7 +1499,8 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "fuse_rows_attn") { e->opt_fuse_rows_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "fuse_rows_mlp") { e->opt_fuse_rows_mlp = value ? 1 : 0; drop_graphs(e); }
-        else if (n == "rows_attn_early") { e->opt_rows_attn_early = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "rows_attn_early") { if (value < 0 || value > 4) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 4"); e->opt_rows_attn_early = (int)value; drop_graphs(e); }
+        else if (n == "rows_mlp_ln2") { e->opt_rows_mlp_ln2 = value ? 1 : 0; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
@@ -1570,6 +1587,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn;
         else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp;
         else if (n == "rows_attn_early") *value = e->opt_rows_attn_early;
+        else if (n == "rows_mlp_ln2") *value = e->opt_rows_mlp_ln2;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;

@@ -56,12 +56,24 @@ struct RowsAttnArgs {
 };
 
 // HASLN: the rows are LayerNorm(sum of PARTS partial buffers [+ pbias + pres when DEFER]); otherwise they come as 16-bit from `xb`
-// EARLY: the first cache round is requested in the kernel's first instructions (true) or only once the row's vectors have arrived (false):
-// A/B switch, engine option rows_attn_early
-template <bool HASLN, int PARTS, bool DEFER, bool EARLY, typename HT>
+// EARLY: when the first cache rounds (64 KB per block and round, 16 MB per launch) are requested.  A CU takes only ~20-25 GB/s from HBM and its
+// requests leave in order, so whatever is asked for in front of the q/k/v exchange delays it by bytes / 20 GB/s: in-kernel stamps show every
+// wave held at the ISSUE of its requests (profiles/r05_decode_step_timeline_b8_*.txt, r05_ab_rows_attn_request_placement.txt; step at 8 rows,
+// kv 3858, same box):
+//   1  both rounds in the kernel's first instructions ............ q/k/v published 8.4-10 us after the block's start, step 1067 us
+//   0  once the rows' vectors have arrived ........................ the same (the 6 MB of q/k/v weights share the memory system with 32 MB of cache), 1065 us
+//   2  both rounds + the out_proj tile behind the q/k/v MFMAs ..... MFMAs done at 1.4 us, but wave 0 reaches its publish 5.5 us later, 1056 us
+//   4  nothing before the exchange is over ....................... exchange over at 6.0 us, the attention starts on a cold stream, 1054 us
+//   3  (default) ONE round behind the MFMAs, by the seven waves that do not publish and sweep; wave 0's own round behind its sweep; the
+//      second round and the out_proj tile once the exchange is over ........................................................ 1043 us
+template <bool HASLN, int PARTS, bool DEFER, int EARLY, int QW, typename HT>
 __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     using G = AttnGeom<HT>;
-    constexpr int K = 1024, NW = 8, KW = K / NW, CH = KW / 32, XS = K + 16;
+    // QW = waves that split K in the q/k/v MFMAs = the split of the launch replaced, so that the sums have the same bits: 8 x 128 where the
+    // launch chain folds LayerNorm 2 into the GEMM (gemm_dec_ln_kernel<.., 8>: every layer but the first), 4 x 256 for layer 0, whose rows
+    // come as 16-bit from the embedding launch (gemm_dec_kernel<1, 8>; waves 4 .. 7 shadow 0 .. 3)
+    static_assert(QW == 8 || (QW == 4 && !HASLN), "K split");
+    constexpr int K = 1024, NW = 8, KW = K / QW, CH = KW / 32, XS = K + 16;
     constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, U = G::U, RPOS = NW * 32;
     static_assert(EPL == 8 && U == 4, "16-bit cache only");
     __shared__ __attribute__((aligned(16))) bf16_t xl[RA_ROWS * XS];       // the eight rows as 16-bit (step C); later the attention output of all rows (step E)
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned kvg[64];              // newest position: k (32 pairs) | v (32 pairs)
     __shared__ float sm[NW * PPW], sl[NW * PPW], so[NW * PPW][64];
     __shared__ float wm_[NW], wl_[NW], wo_[NW][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: branches on w are scalar branches)
     const int m = lane & 15, kg = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
     const int j = 2 * b + z;                                // this block's slice of head h: dims 4 j .. 4 j + 3 of q, k and v
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     }
     asm volatile("" ::: "memory");
     // the q/k/v tile: tile row mm -> row 4 j + (mm & 3) of part mm >> 2 of head h (rows 12 .. 15 repeat the v rows; their outputs are dropped)
-    const int kbase = w * KW + kg * 8;
+    const int kbase = (w % QW) * KW + kg * 8;
     const bf16_t* wrow = a.Wqkv + (size_t)(min(m >> 2, 2) * K + 64 * h + 4 * j + (m & 3)) * K + kbase;
     u32x4 wv[CH];
 #pragma unroll
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) vr[u] = ld_stream16(vh + (size_t)min(base + u * PPW, a.max_seq - 1) * 64);
     };
-    if constexpr (EARLY) early(0, kA, vA);
+    if constexpr (EARLY == 1) early(0, kA, vA);
     asm volatile("" ::: "memory");
     // (a memory clobber orders requests, not arithmetic: hipcc hoists the sums of step B above the weight / cache requests and waits for the row
     //  in front of them.  Passing the row's registers through an empty asm HERE pins their first use behind every request above.)
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
                 s[i].x += va[i].x; s[i].y += va[i].y; s[i].z += va[i].z; s[i].w += va[i].w;
             }
         }
-        if constexpr (EARLY) early(1, kB, vB);              // (the row's vectors have collapsed: registers for the second round)
-        else early(0, kA, vA);
+        if constexpr (EARLY == 1) early(1, kB, vB);         // (the row's vectors have collapsed: registers for the second round)
+        else if constexpr (EARLY == 0) early(0, kA, vA);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(s[i]));
@@ -177,10 +189,10 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             *reinterpret_cast<u32x2*>(&xl[w * XS + idx]) = pack4<HT>(s[i]);
             if (idx >= n0 && idx < n0 + 16) *reinterpret_cast<f32x4*>(&resl[w][idx - n0]) = s[i];
         }
-        if constexpr (!EARLY) early(1, kB, vB);
+        if constexpr (EARLY == 0) early(1, kB, vB);
     } else {
-        if constexpr (!EARLY) early(0, kA, vA);
-        early(1, kB, vB);
+        if constexpr (EARLY == 0) early(0, kA, vA);
+        if constexpr (EARLY < 2) early(1, kB, vB);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&xl[w * XS + (lane + 64 * i) * 8]) = x16[i];
@@ -189,8 +201,10 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     // (four waves x 256; waves 4 .. 7 shadow waves 0 .. 3)
     const bf16_t* worow = a.Wo + (size_t)(n0 + m) * K + (w & 3) * 256 + kg * 8;
     u32x4 wo[8];
+    if constexpr (EARLY < 2) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+        for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+    }
     const f32x4 ob = *reinterpret_cast<const f32x4*>(a.bo + n0 + kg * 4);
     f32x4 rs = {0.f, 0.f, 0.f, 0.f};
     if constexpr (!HASLN) rs = *reinterpret_cast<const f32x4*>(a.res + (size_t)min(m, RA_ROWS - 1) * a.res_stride + n0 + kg * 4);
@@ -205,11 +219,25 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
         for (int s = 0; s < CH; ++s) acc = H16<HT>::mfma16(wv[s], *reinterpret_cast<const u32x4*>(xr + s * 32), acc);
         *reinterpret_cast<f32x4*>(&red[w][lane][0]) = acc;
     }
+    if constexpr (EARLY == 2) {                             // the weights have arrived: now the cache stream (and behind it the out_proj tile)
+        asm volatile("" ::: "memory");
+        early(0, kA, vA);
+        early(1, kB, vB);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+        asm volatile("" ::: "memory");
+    }
+    if constexpr (EARLY == 3) {                             // ... one round, and not by the wave that publishes and sweeps
+        asm volatile("" ::: "memory");
+        if (w != 0) early(0, kA, vA);
+        asm volatile("" ::: "memory");
+    }
     __syncthreads();
+    if (tr && threadIdx.x == 0) tr[1] = __builtin_amdgcn_s_memrealtime();          // q/k/v MFMAs done
     if (w == 0) {
         f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][lane][0]);
 #pragma unroll
-        for (int i = 1; i < NW; ++i) {
+        for (int i = 1; i < QW; ++i) {
             const f32x4 p = *reinterpret_cast<const f32x4*>(&red[i][lane][0]);
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
         }
@@ -226,7 +254,6 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
                 *reinterpret_cast<u32x2*>(plane + (size_t)m * a.kv_row_stride + ((size_t)h * a.max_seq + pos) * 64 + 4 * j) = pk;
             }
         }
-        if (tr && lane == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
         // ---- D.1: the 96 granules of (b, h): lanes 0 .. 31 q and v, lanes 32 .. 63 k --------------------------------------------------
         const gu64* gq = (const gu64*)(a.qkv_gran + (size_t)b * RA_QKV_GRANULES + h * 32);
         const gu64* p1 = gq + (lane < 32 ? lane : 16 * 32 + (lane - 32));
@@ -250,8 +277,16 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             qg[2 * lane] = H16<HT>::lo((unsigned)v1); qg[2 * lane + 1] = H16<HT>::hi((unsigned)v1);
             kvg[32 + lane] = (unsigned)v2;
         } else kvg[lane - 32] = (unsigned)v1;
+        if constexpr (EARLY == 3) early(0, kA, vA);
     }
     __syncthreads();
+    if constexpr (EARLY >= 3) {                             // the exchange is over: the rest of the prefetch depth, and the out_proj tile
+        if constexpr (EARLY == 4) early(0, kA, vA);
+        early(1, kB, vB);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+        asm volatile("" ::: "memory");
+    }
     if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
 
     // ---- D.2: attention over this block's rounds ---------------------------------------------------------------------------------------
@@ -350,9 +385,12 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             L = fmaf(L2, f2, L * f1);
             O = fmaf(O2, f2, O * f1);
             // ---- E.1: the attention output of (b, h), rounded as the out_proj GEMM's operand, two dims per granule ------------------------
-            const float o = O * (1.0f / L);                 // position 0 always exists: L > 0
-            const float on = __shfl_down(o, 1, 64);
-            if (!(lane & 1)) ps_publish(a.out_gran + (size_t)b * RA_OUT_GRANULES + h * 32, lane >> 1, epoch, H16<HT>::pack2(o, on));
+            // (position 0 always exists: L > 0.)  The product is rounded to 16 bits in the SAME expression as in attn_decode_final_kernel: for fp16
+            // hipcc fuses the multiplication and the conversion into one instruction with ONE rounding (v_fma_mixlo_f16); a product kept in fp32
+            // first (to hand it to the neighbour lane) is rounded twice and differs in about one value of 8 000
+            const unsigned ob = H16<HT>::bits(O * (1.0f / L));
+            const unsigned nb = __shfl_down(ob, 1, 64);
+            if (!(lane & 1)) ps_publish(a.out_gran + (size_t)b * RA_OUT_GRANULES + h * 32, lane >> 1, epoch, ob | (nb << 16));
         }
     }
     if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
@@ -411,22 +449,27 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
 }
 
 template <typename HT>
-inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s, bool early_kv = true) {
+inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s, int early_kv = 2, int q_waves = 4) {
     if (heads != 16 || rows != RA_ROWS || !a.Wqkv || !a.Wo || !a.qkv_gran || !a.pair_gran || !a.out_gran || !a.err || !a.y1 || a.y1_stride % 4) return hipErrorInvalidValue;
     const dim3 grid(16, RA_ROWS, 2), block(512);
+    if (early_kv < 0 || early_kv > 4) return hipErrorInvalidValue;
+#define MA_RA(L, P, D, Q) do { if (early_kv == 2) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 2, Q, HT>), grid, block, 0, s, a); \
+                               else if (early_kv == 3) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 3, Q, HT>), grid, block, 0, s, a); \
+                               else if (early_kv == 4) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 4, Q, HT>), grid, block, 0, s, a); \
+                               else if (early_kv == 1) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 1, Q, HT>), grid, block, 0, s, a); \
+                               else hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 0, Q, HT>), grid, block, 0, s, a); } while (0)
     if (!a.ln_g) {
         if (!a.xb || !a.res || a.xb_stride % 8 || a.res_stride % 4) return hipErrorInvalidValue;
-        if (early_kv) hipLaunchKernelGGL((rows_attn_kernel<false, 1, false, true, HT>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((rows_attn_kernel<false, 1, false, false, HT>), grid, block, 0, s, a);
+        if (q_waves == 8) MA_RA(false, 1, false, 8);
+        else if (q_waves == 4) MA_RA(false, 1, false, 4);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (!a.pin || !a.ln_b || a.pin_stride % 4 || (a.pres && a.pres_stride % 4) || (a.pbias != nullptr) != (a.pres != nullptr)) return hipErrorInvalidValue;
     const bool d = a.pres != nullptr;
-#define MA_RA(P, D) do { if (early_kv) hipLaunchKernelGGL((rows_attn_kernel<true, P, D, true, HT>), grid, block, 0, s, a); \
-                         else hipLaunchKernelGGL((rows_attn_kernel<true, P, D, false, HT>), grid, block, 0, s, a); } while (0)
-    if (a.pin_parts == 1 && !d) MA_RA(1, false);
-    else if (a.pin_parts == 2 && d) MA_RA(2, true);
-    else if (a.pin_parts == 4 && d) MA_RA(4, true);
+    if (a.pin_parts == 1 && !d) MA_RA(true, 1, false, 8);
+    else if (a.pin_parts == 2 && d) MA_RA(true, 2, true, 8);
+    else if (a.pin_parts == 4 && d) MA_RA(true, 4, true, 8);
     else return hipErrorInvalidValue;
 #undef MA_RA
     return hipGetLastError();
