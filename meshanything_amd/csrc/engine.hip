@@ -196,6 +196,8 @@ struct ma_engine {
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
     int opt_rows_attn_early = 3;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 3 = one round behind the q/k/v MFMAs, not by the sweeping wave
+    int opt_rows_mlp_prefetch = 1;   // rows_mlp.hpp step F: cache rounds of the next layer pulled into L2 by the blocks that idle during step E (0 = off)
+    unsigned* d_pf_sink = nullptr;
     int opt_rows_mlp_ln2 = 1;        // rows_mlp.hpp step E: LayerNorm 2 finished in the MLP launch (the next q/k/v starts from 16-bit rows)
     u64* d_rm_y2_gran = nullptr;     // its exchange: [max_batch][RM_Y2_GRANULES]
     int opt_fuse_rows_mlp = 1;       // ... and LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp; its relu(fc1) exchange uses d_ffn_gran)
@@ -580,6 +582,11 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
                 if (e->opt_rows_mlp_ln2 && l + 1 < L) {
                     a.b2 = w.fc2_b; a.ln2_g = w.ln2_g; a.ln2_b = w.ln2_b; a.y2_gran = e->d_rm_y2_gran + r0 * RM_Y2_GRANULES;
                     a.x2_out = h0; a.x2_stride = H; a.xb_out = xb; a.xb_stride = H; a.part = nullptr;
+                    if (e->opt_rows_mlp_prefetch > 0 && e->opt_fuse_rows_attn) {
+                        a.pf_k = reinterpret_cast<const bf16_t*>(e->kplane(rw.r0, l + 1)); a.pf_v = reinterpret_cast<const bf16_t*>(e->vplane(rw.r0, l + 1));
+                        a.pf_row_stride = kv_row_elems; a.pf_max_seq = e->maxseq; a.pf_rounds = e->opt_rows_mlp_prefetch;
+                        a.pf_wqkv = reinterpret_cast<const bf16_t*>(e->dl[l + 1].qkv_w); a.pf_sink = e->d_pf_sink;
+                    }
                 }
                 a.trace = tm.trace_slot(4, 256);
                 hipError_t r = H16_CALL(e->hdt, HT, launch_rows_mlp<HT>(a, B, H, c.ffn, s));
@@ -1289,6 +1296,7 @@ void build_engine(ma_engine* e) {
     e->d_ra_qkv_gran = e->dmalloc<u64>(MB * RA_QKV_GRANULES); e->d_ra_out_gran = e->dmalloc<u64>(MB * RA_OUT_GRANULES);
     HIP_CHECK(hipMemset(e->d_ra_qkv_gran, 0, MB * RA_QKV_GRANULES * sizeof(u64)));
     HIP_CHECK(hipMemset(e->d_ra_out_gran, 0, MB * RA_OUT_GRANULES * sizeof(u64)));
+    e->d_pf_sink = e->dmalloc<unsigned>(4);
     e->d_rm_y2_gran = e->dmalloc<u64>(MB * RM_Y2_GRANULES);
     HIP_CHECK(hipMemset(e->d_rm_y2_gran, 0, MB * RM_Y2_GRANULES * sizeof(u64)));
     e->d_ffn_gran = e->dmalloc<u64>(MB * (size_t)c.ffn);
@@ -1501,6 +1509,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "fuse_rows_mlp") { e->opt_fuse_rows_mlp = value ? 1 : 0; drop_graphs(e); }
         else if (n == "rows_attn_early") { if (value < 0 || value > 4) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 4"); e->opt_rows_attn_early = (int)value; drop_graphs(e); }
         else if (n == "rows_mlp_ln2") { e->opt_rows_mlp_ln2 = value ? 1 : 0; drop_graphs(e); }
+        else if (n == "rows_mlp_prefetch") { if (value < 0 || value > 4) throw MaError(MA_ERR_INVALID, "rows_mlp_prefetch: 0 .. 4 rounds"); e->opt_rows_mlp_prefetch = (int)value; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
@@ -1588,6 +1597,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp;
         else if (n == "rows_attn_early") *value = e->opt_rows_attn_early;
         else if (n == "rows_mlp_ln2") *value = e->opt_rows_mlp_ln2;
+        else if (n == "rows_mlp_prefetch") *value = e->opt_rows_mlp_prefetch;
         else if (n == "decode_groups") *value = decode_group_count(e, std::max(1, std::min(e->opt_profile_batch, e->cfg.max_batch)), 0);   // effective, for profile_batch rows
         else if (n == "mfma_fold_fc1_max") *value = e->opt_mfma_fold_fc1_max;
         else if (n == "mfma_fold_qkv_max") *value = e->opt_mfma_fold_qkv_max;

@@ -15,6 +15,11 @@
 //      {epoch, two 16-bit values} granules;
 //   D. every wave sweeps one row's 512 granules of the block's K quarter into LDS; four waves run gemm_dec_kernel<1, 8>'s K split of the
 //      fc2 tile; wave 0 stores the raw partial sums [quarter][row][1024] -- the bits the two-launch form produces;
+//   F. (pf_k != null) L2 prefetch for the next launch by the 248 blocks that have nothing left to do while blocks 0 .. 7 run step E: workgroups go
+//      to the XCDs round-robin (observed; only speed depends on it), so block i of this launch and block i of the next share an L2 -- it reads
+//      what that block will ask for first: its 24 KB of q/k/v weights and its first cache round (64 KB; 16 MB per launch, which the idle HBM
+//      delivers in the ~2.5 us step E takes).  A stream touched by the previous kernel comes back at 15 TB/s instead of 5.5
+//      (profiles/r02_ubench_l2_mall_residency.txt);
 //   E. (ln2_g != null) LayerNorm 2 finished HERE instead of in every block of the next launch (where summing 4 partials + bias + residual of
 //      8 rows was 160 KB of L2 reads per block, 41 MB per launch: 6 of the 10 us before the first q/k/v MFMA, profiles/r05_decode_step_
 //      timeline_b8_*): wave 0 also publishes its partial sums as granules; block r < 8 gathers row r (4096 granules, 8 per thread), adds them in
@@ -47,6 +52,11 @@ struct RowsMlpArgs {
     u64* y2_gran;                                          // [8][RM_Y2_GRANULES]
     float* x2_out; int x2_stride;                          // fp32 LayerNorm 2 output [8][1024]
     bf16_t* xb_out; int xb_stride;                         // ... and as 16-bit
+    // step F (pf_k != null): blocks 8 .. 255, idle while blocks 0 .. 7 finish LayerNorm 2, pull the operands that block (i & 15, (i >> 4) & 7, i >> 7) of
+    // the NEXT layer's rows_attn launch asks for first into this XCD's L2: its q/k/v weight tile and its first `pf_rounds` cache rounds
+    const bf16_t* pf_k; const bf16_t* pf_v; size_t pf_row_stride; int pf_max_seq; int pf_rounds;
+    const bf16_t* pf_wqkv;
+    unsigned* pf_sink;
     unsigned* err;
     unsigned long long* trace;
 };
@@ -209,6 +219,32 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
             ps_publish(g, 2, epoch, __float_as_uint(v.z)); ps_publish(g, 3, epoch, __float_as_uint(v.w));
         }
         if (tr && threadIdx.x == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (a.pf_k && i >= RA_ROWS) {
+        // ---- F: the next launch's first operands -> this XCD's L2 -----------------------------------------------------------------------
+        const int h = i & 15, b = (i >> 4) & 7, z = i >> 7, j = 2 * b + z, g0 = z == 0 ? 1 : 0;
+        const int slot = lane >> 3, dsub = lane & 7;
+        const int end = (int)(epoch - (unsigned)a.layer - 1u) / 32 + 1;          // position + 1 (the epoch is position * 32 + layer + 1)
+        unsigned acc = 0;
+        {   // rows_attn_kernel's weight tile: wave w, lane (m, kg): row 4 j + (m & 3) of part m >> 2 of head h, the eight waves' K split
+            const bf16_t* wrow = a.pf_wqkv + (size_t)(min(m >> 2, 2) * K + 64 * h + 4 * j + (m & 3)) * K + w * KW + kg * 8;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { const u32x4 t = *reinterpret_cast<const u32x4*>(wrow + c * 32); acc ^= t.x ^ t.w; }
+        }
+        const bf16_t* kh = a.pf_k + (size_t)b * a.pf_row_stride + (size_t)h * a.pf_max_seq * 64 + dsub * 8;
+        const bf16_t* vh = a.pf_v + (size_t)b * a.pf_row_stride + (size_t)h * a.pf_max_seq * 64 + dsub * 8;
+        for (int r = 0; r < a.pf_rounds; ++r) {
+            const int base = (g0 + 2 * r) * 256 + w * 32 + slot;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = base + u * 8;
+                const u32x4 tk = *reinterpret_cast<const u32x4*>(kh + (size_t)(p < end ? p : 0) * 64);
+                const u32x4 tv = *reinterpret_cast<const u32x4*>(vh + (size_t)(p < end ? p : 0) * 64);
+                acc ^= tk.x ^ tv.w;
+            }
+        }
+        if (acc == 0x9e3779b9u && a.pf_sink) a.pf_sink[0] = acc;      // (keeps the requests: their data is not used here)
+        return;
     }
     if (!a.ln2_g || i >= RA_ROWS) return;
 

@@ -12,6 +12,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--lens", default="300,3800,7400")
 ap.add_argument("--options", default="")
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--dist", action="store_true", help="also print the distribution over blocks of every stamp of the fused launches")
 a = ap.parse_args()
 cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, max_batch=a.batch)
 eng = Engine(cfg)
@@ -45,3 +46,13 @@ for L in [int(x) for x in a.lens.split(",")]:
     for k in sorted(rows):
         m = np.mean(np.array(rows[k], dtype=np.float64), axis=0) / 100.0
         print(f"{names[k]:8s} {len(rows[k]):3d} {m[0]:10.2f} {m[1]:7.2f} {m[2]:9.2f} {m[3]:7.2f} {m[4]:9.2f} {m[5]:7.2f}")
+    if a.dist:
+        for i in range(len(kinds)):
+            if blocks[i] != 256 or i not in (len(kinds) // 2, len(kinds) // 2 + 1):
+                continue                                   # one first-half and one second-half launch from the middle of the step
+            tk = ticks[i, :256]
+            for j, nm in ((1, "stamp1"), (2, "stamp2"), (3, "stamp3")):
+                d = (tk[:, j] - tk[:, 0])[tk[:, j] > 0] / 100.0
+                if len(d):
+                    q = np.percentile(d, [0, 10, 50, 90, 100])
+                    print(f"   launch {i} ({names[kinds[i]]}) {nm}: {len(d)} blocks, us from the block's start: min {q[0]:.2f} p10 {q[1]:.2f} p50 {q[2]:.2f} p90 {q[3]:.2f} max {q[4]:.2f}")

@@ -109,3 +109,41 @@ def test_oracle_matches_the_diverse_350m_anchors(tag, init, golden_dir, state_di
     dm = torch.from_numpy(a[f"{tag}_detok_margin"])
     ok = valid[:, None] & (dm > 1e-3)
     assert torch.equal(ti[..., 0][ok], torch.from_numpy(a[f"{tag}_detok_bins"]).long()[ok])
+
+
+def test_oracle_matches_the_full_length_anchor(golden_dir, state_dicts):
+    """full_anchor_long.npz (round 5): ONE greedy decode of the reference's own ShapeOPTDecoder.forward over 14 402 tokens (the stream of BASELINE
+    configs[1] = its first 7 202 tokens, and of configs[4]).  The fixture is consistent with the 257-step one (same weights, same cloud: the
+    same first tokens and logits), and the oracle -- teacher-forced in one causal pass over the first MA_TEST_LONG_STEPS tokens (CPU: the
+    whole stream would be 20 TFLOP; the GPU suite walks all of it, tests/test_gpu_long_context.py) -- reproduces the reference's top-8 logits
+    on every step and its token wherever the margin is above rounding."""
+    a = dict(np.load(os.path.join(golden_dir, "full_anchor_long.npz")))
+    h = dict(np.load(os.path.join(golden_dir, "full_anchor_hf.npz")))
+    d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
+    assert int(a["long_complete"][0]) == 1 and len(a["long_tokens"]) == 14402
+    toks_all = torch.from_numpy(a["long_tokens"].astype(np.int64))
+    assert len(set(toks_all[:7202].tolist())) >= 256 and len(set(toks_all.tolist())) >= 400
+    assert int(toks_all.min()) >= 0 and int(toks_all.max()) < 8195 and not bool((toks_all == 1).any())          # eos suppressed
+    assert toks_all[:257].tolist() == h["dva_tokens"].tolist()
+    assert float(np.abs(a["long_top_val"][:257] - h["dva_top_val"][:, :8]).max()) < 2e-5                          # (two runs of the reference, other thread counts)
+    assert np.array_equal(a["long_top_idx"][:, 0].astype(np.int64), a["long_tokens"].astype(np.int64))           # greedy: the token IS the argmax
+    ds = a["long_dense_steps"]
+    assert len(ds) >= 64 and ds[-1] == 14401 and (ds >= 7000).sum() >= 16 and {7186, 7201}.issubset(set(ds.tolist()))
+    n = int(os.environ.get("MA_TEST_LONG_STEPS", "700"))
+    cfg = MAConfig.full()
+    o = Oracle(cfg, state_dicts(cfg, init="diverse"), "fp32")
+    x = torch.from_numpy(d["mouse_norm"])[None]
+    prefix = o.process_point_feature(o.encode_latents(x))
+    assert float(np.abs(prefix[0, :, :8].numpy() - a["long_prefix_cols8"]).max()) < 5e-5
+    lg = o.teacher_forced_logits(prefix, toks_all[:n])[:n].clone()
+    lg[:, 1] = float("-inf")
+    top_i = torch.from_numpy(a["long_top_idx"][:n].astype(np.int64))
+    err = float((lg.gather(1, top_i) - torch.from_numpy(a["long_top_val"][:n])).abs().max())
+    assert err < 5e-4, err
+    clear = torch.from_numpy(a["long_margin"][:n]) > 1e-3
+    assert torch.equal(lg.argmax(dim=1)[clear], toks_all[:n][clear])
+    sel = [(i, int(s)) for i, s in enumerate(ds) if int(s) < n]
+    for i, s in sel:
+        e = max(float((lg[s][torch.from_numpy(a["long_dense_top_idx"][i].astype(np.int64))] - torch.from_numpy(a["long_dense_top_val"][i])).abs().max()),
+                float((lg[s][torch.from_numpy(a["long_dense_cols"].astype(np.int64))] - torch.from_numpy(a["long_dense_logits_cols"][i])).abs().max()))
+        assert e < 5e-4, (s, e)
