@@ -341,22 +341,29 @@ def main():
         fused_o1 = bool(eng.get_option("fuse_oproj_fc1")) and not mfma_path
         fused_f2 = fused_o1 and bool(eng.get_option("fuse_fc2"))
         qkv_w = cfg.layers * 3 * cfg.hidden * cfg.hidden * esz
+        # 8 rows on the matrix-core path: the two-launch layer -- rows_attn_kernel streams q/k/v + out_proj weights AND the cache,
+        # rows_mlp_kernel fc1 + fc2 (csrc/rows_attn.hpp, rows_mlp.hpp); both counted in the class their launch is timed in
+        rows_attn = mfma_path and args.batch == 8 and bool(eng.get_option("fuse_rows_attn")) and bool(eng.get_option("chain_resident"))
+        rows_mlp = mfma_path and args.batch == 8 and bool(eng.get_option("fuse_rows_mlp")) and bool(eng.get_option("chain_resident"))
+        attn_w = cfg.layers * 4 * cfg.hidden * cfg.hidden * esz if rows_attn else (qkv_w if fused_qkv else 0)      # matrices streamed by the cache-class launches
         # the launches of a decode step fall in two classes (ma_profile_decode times each class alone, HIP events on the launch
         # stream around `profile_steps` steps; elapsed / launches = average launch duration, boundary to the next launch included --
         # what a rocprofv3 kernel trace of the same command reports, profiles/):
         #   weights : every launch that streams weight matrices only (gemv_kernel, oproj_fc1_kernel; batched: gemm_dec + prologues)
         #   cache   : the launches that stream the KV cache (attn_decode_kernel, or qkv_attn_kernel = q/k/v weights + cache)
         classes = {}
-        for key, name, byts in (("gemv", "weights", wbytes - (qkv_w if fused_qkv else 0)), ("attn_decode", "cache", kvbytes + (qkv_w if fused_qkv else 0))):
+        for key, name, byts in (("gemv", "weights", wbytes - attn_w), ("attn_decode", "cache", kvbytes + attn_w)):
             n_l = prof["launches"][key]
             per_step = n_l // args.profile_steps
             ms = prof["ms"][key]
             classes[name] = {"launches_per_step": per_step, "launches_timed": n_l, "avg_launch_us": round(ms / max(1, n_l) * 1e3, 3),
                              "bytes_per_launch": int(byts / max(1, per_step)), "GBps": round(byts / max(1, per_step) / (ms / max(1, n_l) * 1e-3) / 1e9, 1),
                              "us_per_step": round(ms / args.profile_steps * 1e3, 1)}
-        kern = {"weights": ("gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream)" if mfma_path else
+        kern = {"weights": ("rows_mlp_kernel (LayerNorm 1 + fc1 + fc2 + LayerNorm 2, 8 rows) + gemv / gemm_dec (embed, lm_head)" if rows_mlp else
+                            "gemm_dec_kernel + rows_prologue_kernel (batched decode weight stream)" if mfma_path else
                             (("oproj_fc1_kernel (out_proj + LN + fc1 + fc2) + gemv_kernel (embed, lm_head)" if fused_f2 else "oproj_fc1_kernel + gemv_kernel (fc2, embed, lm_head)") if fused_o1 else "gemv_kernel") + " -- the launches that stream weight matrices only"),
-                "cache": ("qkv_attn_kernel (q/k/v projection + split-KV attention: q/k/v weights + the KV cache)" if fused_qkv else "attn_decode_kernel (KV cache)")}
+                "cache": ("rows_attn_kernel (8 rows: q/k/v projection + two-block attention + out_proj: their weights + the KV cache)" if rows_attn else
+                          "qkv_attn_kernel (q/k/v projection + split-KV attention: q/k/v weights + the KV cache)" if fused_qkv else "attn_decode_kernel (KV cache)")}
         dom = max(classes, key=lambda k: classes[k]["us_per_step"])          # the class the step spends most of its time in
         dc = classes[dom]
         step_ms = prof["step_ms_graph"] or prof["step_ms_eager"]

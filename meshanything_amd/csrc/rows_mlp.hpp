@@ -19,7 +19,10 @@
 //      to the XCDs round-robin (observed; only speed depends on it), so block i of this launch and block i of the next share an L2 -- it reads
 //      what that block will ask for first: its 24 KB of q/k/v weights and its first cache round (64 KB; 16 MB per launch, which the idle HBM
 //      delivers in the ~2.5 us step E takes).  A stream touched by the previous kernel comes back at 15 TB/s instead of 5.5
-//      (profiles/r02_ubench_l2_mall_residency.txt);
+//      (profiles/r02_ubench_l2_mall_residency.txt).  MEASURED, NOT KEPT (engine option rows_mlp_prefetch, default 0): the next launch does start
+//      faster (q/k/v MFMAs done 1.75 us after the block's start instead of 2.35, exchange over at 5.05 instead of 7.58, kernel 27.8 instead of
+//      30.0 us), but the prefetch outlasts step E and the launch ends 1.7 us later: step 1063 vs 1055 us with one round, 1100 with two, 1052 vs
+//      1052 with half a round (profiles/r05_ab_rows_mlp_prefetch.txt);
 //   E. (ln2_g != null) LayerNorm 2 finished HERE instead of in every block of the next launch (where summing 4 partials + bias + residual of
 //      8 rows was 160 KB of L2 reads per block, 41 MB per launch: 6 of the 10 us before the first q/k/v MFMA, profiles/r05_decode_step_
 //      timeline_b8_*): wave 0 also publishes its partial sums as granules; block r < 8 gathers row r (4096 granules, 8 per thread), adds them in
@@ -233,7 +236,9 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
         }
         const bf16_t* kh = a.pf_k + (size_t)b * a.pf_row_stride + (size_t)h * a.pf_max_seq * 64 + dsub * 8;
         const bf16_t* vh = a.pf_v + (size_t)b * a.pf_row_stride + (size_t)h * a.pf_max_seq * 64 + dsub * 8;
-        for (int r = 0; r < a.pf_rounds; ++r) {
+        // pf_rounds: 1, 2 = that many whole rounds; 8 = the weight tile only; 9 = half of the first round (the waves 0 .. 3 of the block)
+        const int nr = a.pf_rounds == 8 ? 0 : a.pf_rounds == 9 ? (w < 4 ? 1 : 0) : a.pf_rounds;
+        for (int r = 0; r < nr; ++r) {
             const int base = (g0 + 2 * r) * 256 + w * 32 + slot;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
