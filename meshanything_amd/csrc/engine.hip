@@ -195,6 +195,7 @@ struct ma_engine {
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
+    bool rows_ok = false;            // the two 8-row launches (256 blocks of 512 threads each) can be resident all at once on this device
     int opt_rows_attn_early = 3;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 3 = one round behind the q/k/v MFMAs, not by the sweeping wave
     int opt_rows_mlp_prefetch = 0;   // rows_mlp.hpp step F (measured, not kept: 0 = off): the next layer's first operands pulled into L2 by the blocks that idle during step E -- 1 | 2 rounds, 8 = weights only, 9 = half a round
     unsigned* d_pf_sink = nullptr;
@@ -511,7 +512,9 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         const bool pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
         // 8 rows: LayerNorm 2 + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp) -- three launches per layer instead of five.  Its
         // exchange epochs come from DecState.pos (no caller-supplied length), its 256 blocks of 8 waves need every CU (pair_ok's gate)
-        const bool fused_attn = e->opt_fuse_rows_attn && pair_ok && B == RA_ROWS && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && len_override < 0 &&
+        // (row groups stepping on their own streams would put two such launches on the device at once: not with these)
+        const bool rows_gate = e->rows_ok && e->opt_decode_groups <= 1 && pair_ok;
+        const bool fused_attn = e->opt_fuse_rows_attn && rows_gate && B == RA_ROWS && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && len_override < 0 &&
                                 H == 1024 && c.heads == 16 && (fold || ln2_prev);
         if (fused_attn) {
             if (tm.on(1)) {
@@ -569,7 +572,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         ProIn in1;
         if (ks_o_eff > 1 && !fused_attn) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
         // 8 rows: LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp): the same gates as the fused first half, and y1 complete in one buffer
-        const bool fused_mlp = e->opt_fuse_rows_mlp && pair_ok && B == RA_ROWS && len_override < 0 && H == 1024 && c.ffn == 4096 && fold1 && ks_f == 4 && in1.nparts == 1 &&
+        const bool fused_mlp = e->opt_fuse_rows_mlp && rows_gate && B == RA_ROWS && len_override < 0 && H == 1024 && c.ffn == 4096 && fold1 && ks_f == 4 && in1.nparts == 1 &&
                                (size_t)c.ffn >= (size_t)RM_FFN_GRANULES;
         if (fused_mlp) {
             if (tm.on(0)) {
@@ -1328,6 +1331,12 @@ void build_engine(ma_engine* e) {
             const int usable = occ_min > 1 ? occ_min - 1 : occ_min;              // blocks per CU counted on
             e->resident_blocks = (long)e->n_cus * usable;
             e->chain_resident = e->resident_blocks * 4 >= 256L * 5;
+            // the two-launch 8-row layer: 256 blocks of 8 waves at ~190-236 registers = one block per CU -- a register / wave-slot bound, where the
+            // occupancy query is exact: every block must find a CU
+            int occ_ra = 0, occ_rm = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_ra, rows_attn_kernel<true, 4, true, 3, 8, bf16_t>, 512, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_rm, rows_mlp_kernel<bf16_t>, 512, 0) != hipSuccess) { (void)hipGetLastError(); occ_ra = occ_rm = 0; }
+            e->rows_ok = (long)e->n_cus * std::min(occ_ra, occ_rm) >= 256;
 #ifdef MA_EXPERIMENTAL
             // the rows-looped launches: the second one holds 66-130 KB of LDS, i.e. ONE block per CU -- an LDS bound, where the occupancy
             // query is exact (its off-by-one concerns the SGPR-limited high-occupancy cases): 256 blocks need 256 CUs
@@ -1593,8 +1602,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_chunks") *value = gemm_dec_chunks();
         else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
-        else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn;
-        else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp;
+        else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn && e->rows_ok && e->chain_resident;      // as the engine will apply it at 8 rows
+        else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp && e->rows_ok && e->chain_resident;
         else if (n == "rows_attn_early") *value = e->opt_rows_attn_early;
         else if (n == "rows_mlp_ln2") *value = e->opt_rows_mlp_ln2;
         else if (n == "rows_mlp_prefetch") *value = e->opt_rows_mlp_prefetch;

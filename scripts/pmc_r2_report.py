@@ -11,9 +11,9 @@ dec, den, out = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.
 RND = sys.argv[4] if len(sys.argv) > 4 else "r02"
 
 def cls(name):
-    if "qkv_attn_kernel" in name or "attn_decode_kernel" in name:
+    if "qkv_attn_kernel" in name or "attn_decode_kernel" in name or "rows_attn_kernel" in name or "attn_decode_final_kernel" in name:
         return "cache"
-    if "oproj_fc1_kernel" in name or "gemv_kernel" in name:
+    if "oproj_fc1_kernel" in name or "gemv_kernel" in name or "rows_mlp_kernel" in name or "gemm_dec_kernel" in name or "gemm_dec_ln_kernel" in name or "rows_prologue_kernel" in name:
         return "weights"
     return None
 

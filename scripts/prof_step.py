@@ -34,7 +34,7 @@ for opt in a.options.split(";"):
         print(f"[B={a.batch} {opt}] len {L:5d}: step graph {p['step_ms_graph']*1e3:7.1f} us  eager {p['step_ms_eager']*1e3:7.1f} us  per-class(us, event-bracketed eager) {per}", flush=True)
 if a.gen:
     d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dataset.npz"))
-    x = torch.from_numpy(d["mouse_norm"])[None].cuda()
+    x = torch.from_numpy(d["mouse_norm"])[None].expand(a.batch, -1, -1).contiguous().cuda()
     lat, prefix = eng.encode(x)
     torch.cuda.synchronize(); t0 = time.time()
     toks, _ = eng.generate(prefix, suppress_eos=True, max_new_tokens=a.gen)
