@@ -137,12 +137,23 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     const bf16_t* kh = a.kcache + (size_t)b * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * EPL;
     const bf16_t* vh = a.vcache + (size_t)b * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * EPL;
     u32x4 kA[U], vA[U], kB[U], vB[U];
-    auto early = [&](int rr, u32x4 (&kr)[U], u32x4 (&vr)[U]) {          // before the row's length is known: clamped to the plane
+    // Slots past the end: their scores are masked, but their REQUESTS are real.  The first version clamped them to the plane and so streamed
+    // two or three useless rounds per block at short caches (step at kv 600: 717 us; 668 us since).  A slot past the end now asks for the position
+    // of slot 0 of ITS OWN wave-load (the eight positions of a wave-load are one request each: the lanes of a dead slot fold into a live one), for
+    // the newest position if that is dead too (one request for the whole instruction), and a round entirely past the end is not requested at all.
+    // PMC, 256 generated steps at 8 rows (cache 257 .. 513): 23.0 MB per launch against 21.0 MB algorithmic (8.4 MB of q/k/v + out_proj weights
+    // + 8 rows x 385 positions x 4 KB) = 1.10x, profiles/r05_pmc_decode_traffic_b8.json.
+    auto kv_pos = [&](int base, int u) -> size_t {
+        const int p = base + u * PPW, p0 = p - slot;          // this slot's position; slot 0's of the same wave-load
+        return (size_t)(p < end ? p : p0 < end ? p0 : pos);
+    };
+    auto early = [&](int rr, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
+        if ((g0 + 2 * rr) * RPOS >= end) return;              // (block-uniform: the whole round is past the end; its registers are never reduced)
         const int base = (g0 + 2 * rr) * RPOS + w * 32 + slot;
 #pragma unroll
-        for (int u = 0; u < U; ++u) kr[u] = ld_stream16(kh + (size_t)min(base + u * PPW, a.max_seq - 1) * 64);
+        for (int u = 0; u < U; ++u) kr[u] = ld_stream16(kh + kv_pos(base, u) * 64);
 #pragma unroll
-        for (int u = 0; u < U; ++u) vr[u] = ld_stream16(vh + (size_t)min(base + u * PPW, a.max_seq - 1) * 64);
+        for (int u = 0; u < U; ++u) vr[u] = ld_stream16(vh + kv_pos(base, u) * 64);
     };
     if constexpr (EARLY == 1) early(0, kA, vA);
     asm volatile("" ::: "memory");
@@ -295,9 +306,9 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
         const int base = (g0 + 2 * r) * RPOS + w * 32 + slot;
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int p = base + u * PPW; kr[u] = ld_stream16(kh + (size_t)(p < end ? p : 0) * 64); }
+        for (int u = 0; u < U; ++u) kr[u] = ld_stream16(kh + kv_pos(base, u) * 64);
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int p = base + u * PPW; vr[u] = ld_stream16(vh + (size_t)(p < end ? p : 0) * 64); }
+        for (int u = 0; u < U; ++u) vr[u] = ld_stream16(vh + kv_pos(base, u) * 64);
     };
     float qv[EPL];
     {
@@ -309,20 +320,10 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     ss.m = -1e30f; ss.l = 0.f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) ss.o[e] = 0.f;
-    // the early rounds' slots past the end: whatever the plane held there becomes zero before it is used (the reduction masks the score, but
-    // 0 x NaN in the value sum would not be 0) -- inside the loop, so that the second round is not waited for before the first is reduced
-    auto clean = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        const int base = (g0 + 2 * r) * RPOS + w * 32 + slot;
-#pragma unroll
-        for (int u = 0; u < U; ++u) if (base + u * PPW >= end) { kr[u] = zero; vr[u] = zero; }
-    };
     for (int r = 0; r < nround; r += 2) {                   // (rounds 0 and 1 are already on their way)
-        if (r == 0) clean(0, kA, vA);
         attn_round_reduce<HT, true>(ss, qv, kA, vA, (g0 + 2 * r) * RPOS + w * 32 + slot, end, pos, ok4, ov4);
         if (r + 2 < nround) issue(r + 2, kA, vA);
         if (r + 1 < nround) {
-            if (r == 0) clean(1, kB, vB);
             attn_round_reduce<HT, true>(ss, qv, kB, vB, (g0 + 2 * (r + 1)) * RPOS + w * 32 + slot, end, pos, ok4, ov4);
             if (r + 3 < nround) issue(r + 3, kB, vB);
         }

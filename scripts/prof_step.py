@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--options", default="gemv_rpw=1;gemv_rpw=2")
 ap.add_argument("--faces", type=int, default=800)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--no-profile", action="store_true", help="skip the profile_decode sweeps (PMC passes: only the generated steps, cache 257 .. 257 + gen)")
 a = ap.parse_args()
 cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, n_max_faces=a.faces, max_batch=a.batch)
 eng = Engine(cfg)
@@ -27,7 +28,7 @@ for opt in a.options.split(";"):
         if kv:
             k, v = kv.split("=")
             eng.set_option(k, int(v))
-    for L in lens:
+    for L in ([] if a.no_profile else lens):
         eng.profile_decode(L, 2)                      # warm (graph capture, clocks)
         p = eng.profile_decode(L, a.steps)
         per = {k: round(v / a.steps * 1e3, 1) for k, v in p["ms"].items() if p["launches"][k]}
