@@ -215,7 +215,9 @@ def cpu_baseline(cfg: MAConfig, sd, x: torch.Tensor, decode_steps: int = 384, bu
     return {"value": round(tps, 2), "unit": "face-tokens/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 (torch CPU, {cores} threads): encode {t_enc:.2f}s + prefill {t_prefill:.2f}s + {decode_steps} greedy "
                       f"KV-cache decode steps at context {cfg.cond_length}..{cfg.cond_length + decode_steps} ({t_dec:.2f}s); "
-                      f"extrapolated >= {est_mesh:.0f} s/mesh at 800 faces (context grows to {cfg.max_seq})"}
+                      f"extrapolated >= {est_mesh:.0f} s/mesh at 800 faces (context grows to {cfg.max_seq}); the FULL 7202-token run of the same oracle on a gpurun "
+                      f"box's host (16 threads) is committed as profiles/r05_cpu_baseline_full.json: 722.7 s/mesh = 9.96 face-tokens/s, step 49.7 / 65.2 / 303 ms at "
+                      f"context 300 / 3800 / 7400 (the per-step torch.cat of the cache, as transformers 4.39.3 does it, dominates late)"}
 
 
 def main():
@@ -372,7 +374,7 @@ def main():
         # corrected as the MI355X guide prescribes; committed under profiles/): None when no such file is present
         # (a --pmc pass cannot run inside this process: the figure is IMPORTED from the committed profile of the same kernels and labelled so)
         traffic, traffic_source = None, None
-        for name in ("r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
+        for name in ("r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
             f = os.path.join(REPO, "profiles", name)
             if traffic is None and os.path.exists(f) and args.batch == 1 and args.dtype == "bf16" and args.faces == 800:
                 traffic = json.load(open(f)).get("hbm_bytes_per_launch", {}).get(dom)

@@ -351,17 +351,20 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
 #pragma unroll
         for (int u = 0; u < U; ++u) if (base + u * PPW >= end) { kA[u] = zero; vA[u] = zero; }
     }
+    // (a slot past the end asks for the position of slot 0 of its own wave-load -- the eight positions of a wave-load are one request each, so the
+    //  dead slot's lanes fold into a live request -- and only if that is dead too for position 0: these are non-temporal loads, a line asked for
+    //  again is fetched again; the last, partial round of every (row, head) was up to a round of such requests, rows_attn.hpp)
     auto issue = [&](int r, u32x4 (&kr)[U], u32x4 (&vr)[U]) {
         const int base = (g0 + GS * r) * RPOS + w * 32 + slot;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = base + u * PPW;
-            kr[u] = ld_stream16(kh + (size_t)(p < end ? p : 0) * 64);
+            const int p = base + u * PPW, p0 = p - slot;
+            kr[u] = ld_stream16(kh + (size_t)(p < end ? p : p0 < end ? p0 : 0) * 64);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int p = base + u * PPW;
-            vr[u] = ld_stream16(vh + (size_t)(p < end ? p : 0) * 64);
+            const int p = base + u * PPW, p0 = p - slot;
+            vr[u] = ld_stream16(vh + (size_t)(p < end ? p : p0 < end ? p0 : 0) * 64);
         }
     };
     AttnSlotState<KT> ss;

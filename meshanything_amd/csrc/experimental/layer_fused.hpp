@@ -11,8 +11,8 @@
 // publish as well: +2 %).  Opt-in (`fuse_layer`), the default chain keeps two launches per layer.  Hazards inside the launch: the layer-l reads of `res` / the partials finish before a
 // block publishes y1, and nothing of layer l + 1 is written before a block has seen all of y1 -- every block has published by then.
 #pragma once
-#include "oproj_fc1.hpp"
-#include "qkv_attn.hpp"
+#include "../oproj_fc1.hpp"
+#include "../qkv_attn.hpp"
 
 namespace ma {
 

@@ -25,11 +25,11 @@
 // and the engine's error word and leaves; the host turns that into an error after the burst.
 // Eligibility (engine.hip persist_eligible): bf16 policy, batch 1, greedy, hidden 1024 / ffn 4096 / 16 heads, 256 CUs.
 #pragma once
-#include "attn_decode.hpp"
-#include "common.hpp"
-#include "gemv.hpp"
-#include "misc.hpp"
-#include "state.hpp"
+#include "../attn_decode.hpp"
+#include "../common.hpp"
+#include "../gemv.hpp"
+#include "../misc.hpp"
+#include "../state.hpp"
 
 namespace ma {
 

@@ -21,12 +21,12 @@
 // once and the engine re-runs the generation on the launch chain that needs no co-residency (engine.hip generate_batch).
 // Reference: [3p] OPTDecoderLayer + OptFlashAttention2 reached from shape_opt.py:403-410 with a batch of rows (meshanything.py:143-162).
 #pragma once
-#include "attn_decode.hpp"
-#include "common.hpp"
-#include "gemv.hpp"
-#include "oproj_fc1.hpp"
-#include "qkv_attn.hpp"
-#include "state.hpp"
+#include "../attn_decode.hpp"
+#include "../common.hpp"
+#include "../gemv.hpp"
+#include "../oproj_fc1.hpp"
+#include "../qkv_attn.hpp"
+#include "../state.hpp"
 
 namespace ma {
 

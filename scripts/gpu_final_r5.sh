@@ -30,7 +30,7 @@ echo "== PMC passes: decode traffic, batch 1 and 8 rows"
 for B in 1 8; do
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p --output-format csv -- python $R/scripts/prof_step.py --batch $B --options "use_graph=0" --steps 2 --gen 96 > $O/pmc_${C}_b$B.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p --output-format csv -- python $R/scripts/prof_step.py --batch $B --options "use_graph=0" --steps 2 --gen 256 --no-profile > $O/pmc_${C}_b$B.log 2>&1
 done
 python $R/scripts/pmc_summary.py $O/pmc_decode_raw_b$B.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $O/pmc_decode_summary_b$B.log 2>&1
 echo '{}' > $O/empty.json
