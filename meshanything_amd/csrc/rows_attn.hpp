@@ -66,6 +66,17 @@ struct RowsAttnArgs {
 //   4  nothing before the exchange is over ....................... exchange over at 6.0 us, the attention starts on a cold stream, 1054 us
 //   3  (default) ONE round behind the MFMAs, by the seven waves that do not publish and sweep; wave 0's own round behind its sweep; the
 //      second round and the out_proj tile once the exchange is over ........................................................ 1043 us
+// Three 64-byte scalar loads of granules, past the scalar cache (glc).  The scalar unit has its own path to L2: a poll made this way does not
+// queue behind the CU's vector-memory stream (scripts/ubench_poll_under_stream.hip: a sweep by vector loads ends 1.4 - 2.0 us later when the
+// block's other waves have 64 - 112 KB of cache lines requested; by scalar loads from a wave that has no vector requests of its own
+// outstanding, 0.1 - 0.5 us later).  A granule is one aligned 8-byte word written by one store: a 64-byte read returns each of its eight
+// granules whole.
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload3x64_glc(const void* p0, const void* p1, const void* p2, u32x16& a, u32x16& b, u32x16& c) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x0 glc\n\ts_load_dwordx16 %2, %5, 0x0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p0), "s"(p1), "s"(p2) : "memory");
+}
+
 template <bool HASLN, int PARTS, bool DEFER, int EARLY, int QW, typename HT>
 __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     using G = AttnGeom<HT>;
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     const int g0 = z == 0 ? 1 : 0;
     const bf16_t* kh = a.kcache + (size_t)b * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * EPL;
     const bf16_t* vh = a.vcache + (size_t)b * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * EPL;
+    constexpr bool SCAL = EARLY == 5;                       // the q/k/v sweep by scalar loads
     u32x4 kA[U], vA[U], kB[U], vB[U];
     // Slots past the end: their scores are masked, but their REQUESTS are real.  The first version clamped them to the plane and so streamed
     // two or three useless rounds per block at short caches (step at kv 600: 717 us; 668 us since).  A slot past the end now asks for the position
@@ -266,6 +278,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             }
         }
         // ---- D.1: the 96 granules of (b, h): lanes 0 .. 31 q and v, lanes 32 .. 63 k --------------------------------------------------
+        if constexpr (!SCAL) {
         const gu64* gq = (const gu64*)(a.qkv_gran + (size_t)b * RA_QKV_GRANULES + h * 32);
         const gu64* p1 = gq + (lane < 32 ? lane : 16 * 32 + (lane - 32));
         const gu64* p2 = gq + 2 * 16 * 32 + (lane & 31);
@@ -289,16 +302,73 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             kvg[32 + lane] = (unsigned)v2;
         } else kvg[lane - 32] = (unsigned)v1;
         if constexpr (EARLY == 3) early(0, kA, vA);
+        }
+    }
+    if constexpr (SCAL) {
+        // The sweep by SCALAR loads, spread over the waves 0 .. 3 (three 64-byte pieces each: q = pieces 0 .. 3, k = 4 .. 7, v = 8 .. 11), while
+        // the waves 4 .. 7 request their first two cache rounds; the sweeping waves request theirs when they have what they swept for.  The
+        // barrier in front: wave 0's granule stores have been issued before the stream takes the vector-memory path.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // (raw: the stores have been issued; their acknowledgement is not waited for)
+        asm volatile("" ::: "memory");
+        if (w >= 4) {
+            early(0, kA, vA);
+            early(1, kB, vB);
+        } else {
+            const u64* gq = a.qkv_gran + (size_t)b * RA_QKV_GRANULES + h * 32;
+            const int c0 = 3 * w;
+            const u64* pp[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const int c = c0 + i; pp[i] = gq + (size_t)(c >> 2) * 16 * 32 + (c & 3) * 8; }
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            u32x16 g[3];
+            for (;;) {
+                sload3x64_glc(pp[0], pp[1], pp[2], g[0], g[1], g[2]);
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ok = ok && g[i][2 * e + 1] == epoch;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (xchg_expired(spins, t0, a.err)) {
+                    if (lane == 0) xchg_raise(a.err, RA_ERR_QKV);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) g[i] = u32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    break;
+                }
+            }
+            if (lane == 0) xchg_note_slow(a.err, spins, t0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = c0 + i, region = c >> 2, gi = (c & 3) * 8 + lane;      // lane e < 8: granule e of the piece
+                unsigned val = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) val = lane == e ? g[i][2 * e] : val;
+                if (lane < 8) {
+                    if (region == 0) { qg[2 * gi] = H16<HT>::lo(val); qg[2 * gi + 1] = H16<HT>::hi(val); }
+                    else kvg[(region - 1) * 32 + gi] = val;
+                }
+            }
+        }
     }
     __syncthreads();
-    if constexpr (EARLY >= 3) {                             // the exchange is over: the rest of the prefetch depth, and the out_proj tile
-        if constexpr (EARLY == 4) early(0, kA, vA);
-        early(1, kB, vB);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+    if constexpr (SCAL) {                             // (a wave stalls at the issue of a request the CU's path has no room for: behind the barrier)
+        if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
+        if (w < 4) { early(0, kA, vA); early(1, kB, vB); }
         asm volatile("" ::: "memory");
     }
-    if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (EARLY >= 3) {                             // the exchange is over: the rest of the prefetch depth, and the out_proj tile
+        if constexpr (EARLY == 4) early(0, kA, vA);
+        if constexpr (!SCAL) {
+            early(1, kB, vB);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+        }
+        asm volatile("" ::: "memory");
+    }
+    if constexpr (!SCAL) { if (tr && threadIdx.x == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- D.2: attention over this block's rounds ---------------------------------------------------------------------------------------
     const int nr_all = (max(end, 0) + RPOS - 1) / RPOS;
@@ -327,6 +397,15 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             attn_round_reduce<HT, true>(ss, qv, kB, vB, (g0 + 2 * (r + 1)) * RPOS + w * 32 + slot, end, pos, ok4, ov4);
             if (r + 3 < nround) issue(r + 3, kB, vB);
         }
+    }
+    if constexpr (SCAL) {
+        // the out_proj tile: only the 64 blocks that use it ask for it (64 KB of requests per block otherwise, a cache round's worth on the CU's
+        // path), and behind the stream: the merges, the hand-over and the sweep of step E lie between here and its first use
+        if (oproj) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wo[s] = ld_stream16(worow + s * 32);
+        }
+        asm volatile("" ::: "memory");
     }
     // block-level merge (attn_decode_final_kernel: wave w folds its PPW slot states, wave 0 the NW wave states)
     const int gs = w * PPW + slot;
@@ -453,8 +532,9 @@ template <typename HT>
 inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s, int early_kv = 2, int q_waves = 4) {
     if (heads != 16 || rows != RA_ROWS || !a.Wqkv || !a.Wo || !a.qkv_gran || !a.pair_gran || !a.out_gran || !a.err || !a.y1 || a.y1_stride % 4) return hipErrorInvalidValue;
     const dim3 grid(16, RA_ROWS, 2), block(512);
-    if (early_kv < 0 || early_kv > 4) return hipErrorInvalidValue;
+    if (early_kv < 0 || early_kv > 5) return hipErrorInvalidValue;
 #define MA_RA(L, P, D, Q) do { if (early_kv == 2) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 2, Q, HT>), grid, block, 0, s, a); \
+                               else if (early_kv == 5) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 5, Q, HT>), grid, block, 0, s, a); \
                                else if (early_kv == 3) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 3, Q, HT>), grid, block, 0, s, a); \
                                else if (early_kv == 4) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 4, Q, HT>), grid, block, 0, s, a); \
                                else if (early_kv == 1) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 1, Q, HT>), grid, block, 0, s, a); \

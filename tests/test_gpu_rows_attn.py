@@ -90,6 +90,30 @@ def test_fused_halves_are_bitwise_the_five_launches(eng8):
     assert torch.equal(e1, t0[:, :96])
 
 
+def test_request_placements_and_the_scalar_sweep_are_bitwise_the_same(eng8):
+    """Option rows_attn_early: where the first cache rounds are requested inside the first fused launch (0 .. 4: sweep of the q/k/v granules by
+    vector loads of wave 0; 5, the default: by scalar loads -- s_load_dwordx16 glc -- of the waves 0 .. 3 while the waves 4 .. 7 already stream the
+    cache).  A placement decides when bytes move, never which: every form gives the same logits on every step, to a cache of 857 positions
+    (four rounds per (row, head): both register sets re-issued in both blocks of a pair)."""
+    if eng8.get_option("chain_resident") != 1:
+        pytest.skip("the fused launches are not in use on this device")
+    assert eng8.get_option("rows_attn_early") == 5
+    n = 600
+    try:
+        ref = None
+        for early in (5, 0, 1, 2, 3, 4):
+            eng8.set_option("rows_attn_early", early)
+            t, _, g = eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True, return_logits=True)
+            if ref is None:
+                ref = (t, g)
+                continue
+            assert torch.equal(ref[1].view(torch.int32), g.view(torch.int32)) and torch.equal(ref[0], t), f"rows_attn_early={early} differs from the default"
+            del g
+    finally:
+        eng8.set_option("rows_attn_early", 5)
+    assert eng8.get_option("xchg_timeouts") == 0
+
+
 def test_fused_halves_launch_count_and_step_time(eng8):
     """51 launches per step at 8 rows instead of 124 (embedding, 24 x 2, lm_head, pick); A/B of the step at three cache depths."""
     if eng8.get_option("chain_resident") != 1:
