@@ -300,6 +300,19 @@ __device__ __forceinline__ void xchg_note_slow(unsigned* err, unsigned spins, u6
     }
 }
 
+// Three 64-byte scalar loads of granules, past the scalar cache (glc).  The scalar unit has its own path to L2: a poll made this way does not
+// queue behind the CU's vector-memory stream (scripts/ubench_poll_under_stream.hip: a sweep by vector loads ends 1.4 - 2.0 us later when the
+// block's other waves have 64 - 112 KB of cache lines requested; by scalar loads from a wave that has no vector requests of its own
+// outstanding, 0.1 - 0.5 us later; a wave that HAS stalls at their issue first).  A granule is one aligned 8-byte word written by one store:
+// a 64-byte read returns each of its eight granules whole.  The pointers must be wave-uniform.
+// (Batch 1, qkv_attn.hpp: measured slower than the vector sweep -- nothing streams under that exchange at short caches, and a scalar round
+// trip is the longer one: profiles/r05_ab_qkv_attn_scalar_sweep_batch1.txt.)
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload3x64_glc(const void* p0, const void* p1, const void* p2, u32x16& a, u32x16& b, u32x16& c) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x0 glc\n\ts_load_dwordx16 %2, %5, 0x0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p0), "s"(p1), "s"(p2) : "memory");
+}
+
 // better-argmax: larger value wins, ties -> lower index (torch.argmax semantics)
 __device__ inline bool arg_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 

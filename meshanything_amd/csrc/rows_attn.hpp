@@ -66,17 +66,6 @@ struct RowsAttnArgs {
 //   4  nothing before the exchange is over ....................... exchange over at 6.0 us, the attention starts on a cold stream, 1054 us
 //   3  (default) ONE round behind the MFMAs, by the seven waves that do not publish and sweep; wave 0's own round behind its sweep; the
 //      second round and the out_proj tile once the exchange is over ........................................................ 1043 us
-// Three 64-byte scalar loads of granules, past the scalar cache (glc).  The scalar unit has its own path to L2: a poll made this way does not
-// queue behind the CU's vector-memory stream (scripts/ubench_poll_under_stream.hip: a sweep by vector loads ends 1.4 - 2.0 us later when the
-// block's other waves have 64 - 112 KB of cache lines requested; by scalar loads from a wave that has no vector requests of its own
-// outstanding, 0.1 - 0.5 us later).  A granule is one aligned 8-byte word written by one store: a 64-byte read returns each of its eight
-// granules whole.
-typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void sload3x64_glc(const void* p0, const void* p1, const void* p2, u32x16& a, u32x16& b, u32x16& c) {
-    asm volatile("s_load_dwordx16 %0, %3, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x0 glc\n\ts_load_dwordx16 %2, %5, 0x0 glc\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p0), "s"(p1), "s"(p2) : "memory");
-}
-
 template <bool HASLN, int PARTS, bool DEFER, int EARLY, int QW, typename HT>
 __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     using G = AttnGeom<HT>;
