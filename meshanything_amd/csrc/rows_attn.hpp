@@ -64,8 +64,13 @@ struct RowsAttnArgs {
 //   0  once the rows' vectors have arrived ........................ the same (the 6 MB of q/k/v weights share the memory system with 32 MB of cache), 1065 us
 //   2  both rounds + the out_proj tile behind the q/k/v MFMAs ..... MFMAs done at 1.4 us, but wave 0 reaches its publish 5.5 us later, 1056 us
 //   4  nothing before the exchange is over ....................... exchange over at 6.0 us, the attention starts on a cold stream, 1054 us
-//   3  (default) ONE round behind the MFMAs, by the seven waves that do not publish and sweep; wave 0's own round behind its sweep; the
+//   3  ONE round behind the MFMAs, by the seven waves that do not publish and sweep; wave 0's own round behind its sweep; the
 //      second round and the out_proj tile once the exchange is over ........................................................ 1043 us
+//   5  (default) the sweep by SCALAR loads of the waves 0 .. 3 (their own path to L2: not behind the stream) while the waves 4 .. 7 request
+//      both rounds; the sweeping waves' rounds behind the exchange barrier; the out_proj tile by the 64 blocks that use it, behind the
+//      stream: exchange over at 4.2 us instead of 7.7 ........................................ 1029 us where 3 gives 1051 (another box)
+// (steps A - E above describe placement 1 / the vector sweep; with 5, step D's sweep is the scalar one and the out_proj tile of step E is
+//  requested after the block's last round)
 template <bool HASLN, int PARTS, bool DEFER, int EARLY, int QW, typename HT>
 __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     using G = AttnGeom<HT>;
