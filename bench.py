@@ -380,6 +380,12 @@ def main():
                 traffic = json.load(open(f)).get("hbm_bytes_per_launch", {}).get(dom)
                 if traffic is not None:
                     traffic_source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; imported, NOT measured by this run)"
+        # 8 rows: the PMC pass of the two fused launches at THIS cache length (profile_decode steps only, scripts/gpu_pmc_b8_mid.sh)
+        f8 = os.path.join(REPO, "profiles", "r05_pmc_decode_traffic_b8_kv3858.json")
+        if traffic is None and rows_attn and rows_mlp and args.dtype == "bf16" and mid == 3858 and os.path.exists(f8):
+            traffic = json.load(open(f8)).get("hbm_bytes_per_launch", {}).get(dom)
+            if traffic is not None:
+                traffic_source = "profiles/r05_pmc_decode_traffic_b8_kv3858.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over decode steps at this cache length; imported, NOT measured by this run)"
         roofline = {"bound": "hbm", "kernel": f"{kern[dom]}, {dc['launches_per_step']} launches per step", "achieved": dc["GBps"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dc["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "bytes_per_launch": dc["bytes_per_launch"], "avg_launch_us": dc["avg_launch_us"], "launches_timed": dc["launches_timed"],

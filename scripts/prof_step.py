@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--options", default="gemv_rpw=1;gemv_rpw=2")
 ap.add_argument("--faces", type=int, default=800)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--lens", default="", help="cache lengths of the profile_decode sweeps (default: 300, 1000, 3800 and the maximum)")
 ap.add_argument("--no-profile", action="store_true", help="skip the profile_decode sweeps (PMC passes: only the generated steps, cache 257 .. 257 + gen)")
 a = ap.parse_args()
 cfg = MAConfig.full(dtype=DTYPE_BF16 if a.dtype == "bf16" else DTYPE_F32, n_max_faces=a.faces, max_batch=a.batch)
@@ -22,7 +23,7 @@ t0 = time.time()
 eng.load_weights(synthetic_items(cfg))
 print(f"weights loaded in {time.time()-t0:.1f}s", flush=True)
 eng.set_option("profile_batch", a.batch)
-lens = [300, 1000, 3800, cfg.max_seq - 3 * a.steps - 16]
+lens = [int(v) for v in a.lens.split(",")] if a.lens else [300, 1000, 3800, cfg.max_seq - 3 * a.steps - 16]
 for opt in a.options.split(";"):
     for kv in opt.split(","):
         if kv:
