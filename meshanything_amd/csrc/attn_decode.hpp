@@ -91,7 +91,9 @@ template <typename KT> struct AttnSlotState { float m, l, o[16 / sizeof(KT)]; };
 // one round: the U positions base + u * PPW of this lane's slot (positions >= end are masked), one rescale per round.
 // OVR: position ovr_pos takes its K / V rows from (ovr_k, ovr_v) instead of the loaded registers (persistent kernel: the
 // newest position has not reached the cache yet).
-template <typename KT, bool OVR>
+// FULL: the caller knows that every position of the round is below `end` (and, with OVR false, that none is the overridden one): the masks
+// are dropped -- the same arithmetic on the same values, about a quarter fewer instructions (selects, compares) per round.
+template <typename KT, bool OVR, bool FULL = false>
 __device__ __forceinline__ void attn_round_reduce(AttnSlotState<KT>& st, const float (&qv)[16 / sizeof(KT)], const u32x4 (&kr)[AttnGeom<KT>::U],
                                                   const u32x4 (&vr)[AttnGeom<KT>::U], int base, int end, int ovr_pos, const u32x4& ovr_k,
                                                   const u32x4& ovr_v) {
@@ -107,7 +109,7 @@ __device__ __forceinline__ void attn_round_reduce(AttnSlotState<KT>& st, const f
 #pragma unroll
         for (int e = 0; e < G::EPL; ++e) t = fmaf(qv[e], kf[e], t);
         t = group_sum<G::LPP>(t) * 0.125f;                 // 1/sqrt(64)
-        d[u] = (base + u * G::PPW < end) ? t : -1e30f;
+        d[u] = (FULL || base + u * G::PPW < end) ? t : -1e30f;
         mr = fmaxf(mr, d[u]);
     }
     const float alpha = expf(st.m - mr);                   // one rescale per round
@@ -119,7 +121,7 @@ __device__ __forceinline__ void attn_round_reduce(AttnSlotState<KT>& st, const f
         float vf[G::EPL];
         if constexpr (OVR) attn_unpack<KT>(base + u * G::PPW == ovr_pos ? ovr_v : vr[u], vf);
         else attn_unpack<KT>(vr[u], vf);
-        const float pexp = (base + u * G::PPW < end) ? expf(d[u] - mr) : 0.f;
+        const float pexp = (FULL || base + u * G::PPW < end) ? expf(d[u] - mr) : 0.f;
         st.l += pexp;
 #pragma unroll
         for (int e = 0; e < G::EPL; ++e) st.o[e] = fmaf(pexp, vf[e], st.o[e]);

@@ -308,7 +308,13 @@ __device__ __forceinline__ void xchg_note_slow(unsigned* err, unsigned spins, u6
 // (Batch 1, qkv_attn.hpp: measured slower than the vector sweep -- nothing streams under that exchange at short caches, and a scalar round
 // trip is the longer one: profiles/r05_ab_qkv_attn_scalar_sweep_batch1.txt.)
 typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ const void* sgpr_ptr(const void* p) {          // (an "s" operand must BE in scalar registers: not left to the optimiser -- the -O1 / ASan build)
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ void sload3x64_glc(const void* p0, const void* p1, const void* p2, u32x16& a, u32x16& b, u32x16& c) {
+    p0 = sgpr_ptr(p0); p1 = sgpr_ptr(p1); p2 = sgpr_ptr(p2);
     asm volatile("s_load_dwordx16 %0, %3, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x0 glc\n\ts_load_dwordx16 %2, %5, 0x0 glc\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(p0), "s"(p1), "s"(p2) : "memory");
 }

@@ -196,7 +196,7 @@ struct ma_engine {
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
     bool rows_ok = false;            // the two 8-row launches (256 blocks of 512 threads each) can be resident all at once on this device
-    int opt_rows_attn_early = 5;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 5 = the q/k/v sweep by scalar loads (waves 0 .. 3), two rounds by the waves 4 .. 7 meanwhile; 3 = one round behind the q/k/v MFMAs, sweep by vector loads
+    int opt_rows_attn_early = 6;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 5 = the q/k/v sweep by scalar loads (waves 0 .. 3), two rounds by the waves 4 .. 7 meanwhile; 6 = 5 + rounds wholly below the newest position run without masks; 3 = one round behind the q/k/v MFMAs, sweep by vector loads
     int opt_rows_mlp_prefetch = 0;   // rows_mlp.hpp step F (measured, not kept: 0 = off): the next layer's first operands pulled into L2 by the blocks that idle during step E -- 1 | 2 rounds, 8 = weights only, 9 = half a round
     unsigned* d_pf_sink = nullptr;
     int opt_rows_mlp_ln2 = 1;        // rows_mlp.hpp step E: LayerNorm 2 finished in the MLP launch (the next q/k/v starts from 16-bit rows)
@@ -1516,7 +1516,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "fuse_rows_attn") { e->opt_fuse_rows_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "fuse_rows_mlp") { e->opt_fuse_rows_mlp = value ? 1 : 0; drop_graphs(e); }
-        else if (n == "rows_attn_early") { if (value < 0 || value > 5) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 5"); e->opt_rows_attn_early = (int)value; drop_graphs(e); }
+        else if (n == "rows_attn_early") { if (value < 0 || value > 6) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 6"); e->opt_rows_attn_early = (int)value; drop_graphs(e); }
         else if (n == "rows_mlp_ln2") { e->opt_rows_mlp_ln2 = value ? 1 : 0; drop_graphs(e); }
         else if (n == "rows_mlp_prefetch") { if (value < 0 || value > 9) throw MaError(MA_ERR_INVALID, "rows_mlp_prefetch: 0 off, 1 / 2 rounds, 8 weights only, 9 half a round"); e->opt_rows_mlp_prefetch = (int)value; drop_graphs(e); }
         else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }

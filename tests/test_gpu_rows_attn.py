@@ -92,16 +92,16 @@ def test_fused_halves_are_bitwise_the_five_launches(eng8):
 
 def test_request_placements_and_the_scalar_sweep_are_bitwise_the_same(eng8):
     """Option rows_attn_early: where the first cache rounds are requested inside the first fused launch (0 .. 4: sweep of the q/k/v granules by
-    vector loads of wave 0; 5, the default: by scalar loads -- s_load_dwordx16 glc -- of the waves 0 .. 3 while the waves 4 .. 7 already stream the
-    cache).  A placement decides when bytes move, never which: every form gives the same logits on every step, to a cache of 857 positions
+    vector loads of wave 0; 5: by scalar loads -- s_load_dwordx16 glc -- of the waves 0 .. 3 while the waves 4 .. 7 already stream the cache; 6, the
+    default: 5 + the rounds that lie wholly below the newest position reduced without masks and override).  A placement decides when bytes move, never which: every form gives the same logits on every step, to a cache of 857 positions
     (four rounds per (row, head): both register sets re-issued in both blocks of a pair)."""
     if eng8.get_option("chain_resident") != 1:
         pytest.skip("the fused launches are not in use on this device")
-    assert eng8.get_option("rows_attn_early") == 5
+    assert eng8.get_option("rows_attn_early") == 6
     n = 600
     try:
         ref = None
-        for early in (5, 0, 1, 2, 3, 4):
+        for early in (6, 0, 1, 2, 3, 4, 5):
             eng8.set_option("rows_attn_early", early)
             t, _, g = eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True, return_logits=True)
             if ref is None:
@@ -110,7 +110,7 @@ def test_request_placements_and_the_scalar_sweep_are_bitwise_the_same(eng8):
             assert torch.equal(ref[1].view(torch.int32), g.view(torch.int32)) and torch.equal(ref[0], t), f"rows_attn_early={early} differs from the default"
             del g
     finally:
-        eng8.set_option("rows_attn_early", 5)
+        eng8.set_option("rows_attn_early", 6)
     assert eng8.get_option("xchg_timeouts") == 0
 
 
