@@ -211,6 +211,7 @@ struct ma_engine {
     bool persist_shape = false;      // shape / device eligibility (fixed at creation)
     bool chain_resident = false;     // the fused launches' 256 blocks fit on the device at once, with margin (their in-launch exchange needs that)
     long resident_blocks = 0;        // 256-thread blocks of the fused launches the device holds at once (CUs x (occupancy - 1))
+    int xchg_last_code = 0;          // the error word of the last generation that fell back (bits of the sweeps that gave up)
     int chain_fallbacks = 0;         // generations that were re-run on the five-launch chain after an exchange timed out
     int gens_since_fallback = 0;     // clean generations on the five-launch chain since then: after CHAIN_REARM_AFTER of them the fused launches get another try
     bool embtab_ready = false;
@@ -868,6 +869,7 @@ void check_chain_error(ma_engine* e, hipStream_t s) {
     HIP_CHECK(hipMemcpyAsync(e->h_chain_err, e->d_chain_err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     if (*e->h_chain_err) {
+        e->xchg_last_code = (int)*e->h_chain_err;            // which sweep(s) gave up: QA_ERR_GATHER 16 | OF_ERR_GATHER 32 | attention pair 64 | RA_ERR_QKV 256 | RA_ERR_OUT 512 | RM_ERR_FFN 1024 ...
         HIP_CHECK(hipMemsetAsync(e->d_chain_err, 0, sizeof(unsigned), s));
         throw ChainTimeout("a fused decode launch's in-launch exchange timed out (not all blocks of the grid resident?)");
     }
@@ -1289,7 +1291,7 @@ void build_engine(ma_engine* e) {
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
-    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(4);      // [0] error bits (cleared when read), [1] expiries ever, [2] longest slow block (ticks), [3] slow blocks ever
+    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(8);      // [0] error bits (cleared when read), [1] expiries ever, [2] longest slow block (ticks), [3] slow blocks ever, [4] scalar sweeps rescued by a vector look (rows_attn.hpp)
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
     e->d_attn_pair_gran = e->dmalloc<unsigned long long>(MB * c.heads * ATTN_PAIR_GRANULES);
@@ -1309,7 +1311,7 @@ void build_engine(ma_engine* e) {
     HIP_CHECK(hipMemset(e->d_part_gran, 0, MB * (size_t)c.heads * ATTN_NCHUNK * RF_PART * sizeof(u64)));
 #endif
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
-    HIP_CHECK(hipMemset(e->d_chain_err, 0, 4 * sizeof(unsigned)));
+    HIP_CHECK(hipMemset(e->d_chain_err, 0, 8 * sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
@@ -1584,12 +1586,14 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "persist_available") *value = e->persist_shape ? 1 : 0;
         else if (n == "chain_resident") *value = e->chain_resident ? 1 : 0;
         else if (n == "chain_fallbacks") *value = e->chain_fallbacks;
-        else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us") {
-            // device counters of the fused launches, never cleared: sweeps that ever gave up | blocks that lived > 1 ms | the longest of them
-            unsigned v[4] = {0, 0, 0, 0};
+        else if (n == "xchg_last_code") *value = e->xchg_last_code;
+        else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us" || n == "scalar_sweep_rescues") {
+            // device counters of the fused launches, never cleared: sweeps that ever gave up | blocks that lived > 1 ms | the longest of them |
+            // scalar sweeps that a vector look had to finish
+            unsigned v[5] = {0, 0, 0, 0, 0};
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipMemcpy(v, e->d_chain_err, sizeof(v), hipMemcpyDeviceToHost));
-            *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : v[2] / 100;
+            *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : n == "scalar_sweep_rescues" ? v[4] : v[2] / 100;
         }
         else if (n == "resident_blocks") *value = e->resident_blocks;
         else if (n == "use_graph") *value = e->cfg.use_graph;

@@ -328,6 +328,24 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ok = ok && g[i][2 * e + 1] == epoch;
                 if (ok) break;
+                if (spins >= 48u && (spins & 15u) == 0u) {
+                    // Insurance: the protocol of every other sweep (agent-scope vector loads, which the memory model defines) looks at the same 24
+                    // granules; if THEY carry the epoch while the scalar reads do not, the scalar path served stale bytes -- take the vector
+                    // values and count the event (err[4], ma_engine_get_option "scalar_sweep_rescues"; never seen in 10^6 sweeps of the tests).
+                    const int li = lane < 24 ? lane : 0;
+                    const u64 vv = __hip_atomic_load((const gu64*)pp[li >> 3] + (li & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((unsigned)(vv >> 32) == epoch)) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const u64 t = __shfl(vv, i * 8 + e);
+                                g[i][2 * e] = __builtin_amdgcn_readfirstlane((unsigned)t); g[i][2 * e + 1] = epoch;
+                            }
+                        if (lane == 0) __hip_atomic_fetch_add(a.err + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
                     if (lane == 0) xchg_raise(a.err, RA_ERR_QKV);

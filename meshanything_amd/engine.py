@@ -317,7 +317,7 @@ class Engine:
         if n > seen:
             import warnings
             warnings.warn(f"meshanything_amd: the fused decode launches timed out {n - seen} time(s) (shared device?); the generation re-ran on "
-                          f"the launch chain (same results, slower decode step); chain_fallbacks = {n}", RuntimeWarning, stacklevel=3)
+                          f"the launch chain (same results, slower decode step); chain_fallbacks = {n}, error word {self.get_option('xchg_last_code')}", RuntimeWarning, stacklevel=3)
             self._fallbacks_seen = n
 
     def trace_decode(self, kv_len: int, max_launches: int = 160, max_blocks: int = 2560) -> Dict[str, np.ndarray]:
