@@ -105,7 +105,8 @@ typedef struct ma_sample_cfg {
     int32_t max_new_tokens; /* <= 9*n_max_faces + 2; 0 = that maximum */
     int32_t suppress_eos;   /* 1: never emit eos (full-length throughput runs on random weights) */
     int32_t check_every;    /* poll the all-rows-finished flag every this many steps (0 = 64) */
-    int32_t logits_first_step; /* with logits_out: the first step whose logits are kept (0 = all); see logits_out */
+    int32_t logits_first_step; /* with logits_out: the first step whose logits are kept, in [0, max_new_tokens) (0 = all; outside that range:
+                                  MA_ERR_INVALID); ignored, whatever its value, when logits_out is NULL; see logits_out */
     uint64_t seed;          /* in-kernel uniform stream when `uniforms` is NULL */
     const float *uniforms;  /* DEVICE (B, max_new_tokens) uniforms in [0,1), or NULL.  Injected uniforms define
                                sampling parity with the oracle (the reference's Philox stream is not reproducible). */

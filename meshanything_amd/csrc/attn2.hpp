@@ -87,8 +87,11 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
 }
 
 // HT: the 16-bit format of Q / K / V^T / O (bf16_t | f16_t, common.hpp H16)
+// Three waves per SIMD (launch bound): the 96-row form came out at 169 registers -- ONE over the step to three waves per SIMD -- so a CU held two
+// blocks of it, and a block is a chain of latencies (Q and the first tile, then one round trip per tile: 9 % matrix-core busy, r04_pmc_dense_mfma).
+// With the bound a dozen loop-invariant addresses go to scratch around the loop (none inside it) and a CU holds four blocks.
 template <int NW, typename HT = bf16_t>
-__global__ __launch_bounds__(NW * 64) void attention_mfma2_kernel(Attn2Args a) {
+__global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a) {
     constexpr int NT = NW * 64, RB = NW * 32, TILE = 64 * 128;         // threads, query rows per block, bytes of one K or V^T tile
     constexpr int NCH = (512 + NT - 1) / NT;                            // 16-byte chunks per thread, tile and operand
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // ring of two stages x {K, V^T}; reused for the output patches

@@ -16,12 +16,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // fp32 -> bf16 bits, round-to-nearest-even (NaN kept quiet).  Matches torch .to(bfloat16) and checkpoint.bf16_round.
+// Device code takes gfx950's conversion instruction (v_cvt_pk_bf16_f32 behind the __bf16 cast): the same bits as the integer form below for
+// every non-NaN input (all 2^32 patterns compared on the GPU: scripts/ubench_gemm256_epi.hip, profiles/r06_ubench_gemm256_epi.txt) at one
+// instruction per PAIR instead of ~10 with a divergent NaN branch per element -- the integer form was half of the 256 x 256 GEMM's epilogue.
 __host__ __device__ inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);
+#else
     union { float f; uint32_t u; } v; v.f = f;
     uint32_t u = v.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
 }
 __host__ __device__ inline float bf2f(bf16_t b) {
     union { float f; uint32_t u; } v; v.u = ((uint32_t)b) << 16; return v.f;
@@ -83,7 +90,11 @@ template <> struct H16<bf16_t> {
     static __device__ __forceinline__ float one(uint16_t b) { return bf2f(b); }
     static __device__ __forceinline__ uint16_t bits(float f) { return f2bf(f); }
     static __device__ __forceinline__ float round(float f) { return bf2f(f2bf(f)); }
-    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+    }
     static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }

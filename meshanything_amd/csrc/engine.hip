@@ -467,6 +467,31 @@ void gemm_dec(ma_engine* e, hipStream_t s, GemmDecArgs a, StepTimer& tm, int kin
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("gemm_dec launch failed: ") + hipGetErrorString(r));
 }
 
+// The gates of the two 8-row launches (rows_attn.hpp, rows_mlp.hpp) that do not depend on the layer -- ONE definition for the step builder
+// below and for ma_engine_get_option("fuse_rows_attn" / "fuse_rows_mlp"), which bench.py uses to label the roofline kernel.
+struct RowsGates {
+    bool fold1, fold;                 // LayerNorm 1 inside fc1 / LayerNorm 2 inside q/k/v (gemm_dec_ln_kernel)
+    int ks_f;                         // split of fc2 along K
+    bool pair_ok;                     // the two-block final-form attention: both blocks of every (row, head) resident together
+    bool attn, mlp;                   // the fused first / second half of a layer, as far as the layer index does not matter
+};
+RowsGates rows_gates(ma_engine* e, int B, int len_override) {
+    const ma_config& c = e->cfg;
+    const int H = c.hidden;
+    RowsGates g{};
+    g.fold1 = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_fc1_max && B <= 16 && H == 1024;
+    g.fold = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_qkv_max && B <= 16 && H == 1024;
+    g.ks_f = e->opt_mfma_fc2_ksplit ? e->opt_mfma_fc2_ksplit : gemm_dec_ksplit(H, c.ffn);
+    // (the hand-over epoch is position * 32 + layer + 1: more than 31 layers would alias the next position's layer 0)
+    g.pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
+    // exchange epochs come from DecState.pos (no caller-supplied length); 256 blocks of 8 waves need every CU (pair_ok's gate); row groups
+    // stepping on their own streams would put two such launches on the device at once: not with these
+    const bool gate = e->rows_ok && e->opt_decode_groups <= 1 && g.pair_ok && B == RA_ROWS && len_override < 0 && H == 1024;
+    g.attn = e->opt_fuse_rows_attn && gate && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && c.heads == 16;
+    g.mlp = e->opt_fuse_rows_mlp && gate && c.ffn == 4096 && g.fold1 && g.ks_f == 4 && (size_t)c.ffn >= (size_t)RM_FFN_GRANULES;
+    return g;
+}
+
 // The 24 OPT layers + lm_head of one decode step for a batch on the matrix cores (gemm_decode.hpp).  Same data flow as the
 // GEMV path; the prologues are one-block-per-row launches, and the two N = hidden GEMMs (out_proj, fc2) are split along K
 // with their bias / residual folded into the LayerNorm prologue that follows them.
@@ -484,13 +509,14 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
     float* partO = e->d_ks_o + 4 * r0 * H; float* partF = e->d_ks_f + 4 * r0 * H;
     (void)MB;
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
-    const int ks_o = gemm_dec_ksplit(H, H), ks_f = e->opt_mfma_fc2_ksplit ? e->opt_mfma_fc2_ksplit : gemm_dec_ksplit(H, c.ffn);
+    const RowsGates rg = rows_gates(e, B, len_override);
+    const int ks_o = gemm_dec_ksplit(H, H), ks_f = rg.ks_f;
     // 4..16 rows: the LayerNorm prologues run inside the consuming GEMMs (gemm_dec_ln_kernel) and out_proj is not split along K, so
     // that its epilogue finishes y1: two launches fewer per layer
     // (the folded prologue reads its inputs once per block: 1 buffer in front of fc1, 4 split-K partials + residual in front of q/k/v, so
     //  the second stops paying earlier: profiles/r02_ab_batched_ln_fold.txt)
-    const bool fold1 = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_fc1_max && B <= 16 && H == 1024;      // LN1 inside fc1
-    const bool fold = e->opt_mfma_fold_ln && B <= e->opt_mfma_fold_qkv_max && B <= 16 && H == 1024;       // LN2 inside q/k/v
+    const bool fold1 = rg.fold1;                                // LN1 inside fc1
+    const bool fold = rg.fold;                                  // LN2 inside q/k/v
     const int ks_o_eff = fold1 ? 1 : ks_o;
     bool ln2_prev = false;                                      // the previous layer's MLP launch finished its LayerNorm 2 (rows_mlp.hpp step E): xb and h0 are ready
     for (int l = 0; l < L; ++l) {
@@ -509,14 +535,9 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
             resid = h0;
         }
         // the two-block final-form attention needs both blocks of every (row, head) resident together: 2 B heads <= CUs (8 rows on an MI355X)
-        // (its hand-over epoch is position * 32 + layer + 1: more than 31 layers would alias the next position's layer 0)
-        const bool pair_ok = e->opt_attn_pair && e->chain_resident && c.layers <= 31 && 2 * B * c.heads <= e->n_cus && (e->opt_attn_final_waves == 0 || e->opt_attn_final_waves == 8);
-        // 8 rows: LayerNorm 2 + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp) -- three launches per layer instead of five.  Its
-        // exchange epochs come from DecState.pos (no caller-supplied length), its 256 blocks of 8 waves need every CU (pair_ok's gate)
-        // (row groups stepping on their own streams would put two such launches on the device at once: not with these)
-        const bool rows_gate = e->rows_ok && e->opt_decode_groups <= 1 && pair_ok;
-        const bool fused_attn = e->opt_fuse_rows_attn && rows_gate && B == RA_ROWS && 2 * B * c.heads == 256 && B >= e->opt_attn_final_min_batch && len_override < 0 &&
-                                H == 1024 && c.heads == 16 && (fold || ln2_prev);
+        const bool pair_ok = rg.pair_ok;
+        // 8 rows: LayerNorm 2 + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp) -- three launches per layer instead of five (gates: rows_gates)
+        const bool fused_attn = rg.attn && (fold || ln2_prev);
         if (fused_attn) {
             if (tm.on(1)) {
                 RowsAttnArgs a{};
@@ -573,8 +594,7 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
         ProIn in1;
         if (ks_o_eff > 1 && !fused_attn) { in1.x = partO; in1.nparts = ks_o_eff; in1.bias = w.o_b; in1.res = resid; } else in1.x = y1;
         // 8 rows: LayerNorm 1 + fc1 + fc2 in ONE launch (rows_mlp.hpp): the same gates as the fused first half, and y1 complete in one buffer
-        const bool fused_mlp = e->opt_fuse_rows_mlp && rows_gate && B == RA_ROWS && len_override < 0 && H == 1024 && c.ffn == 4096 && fold1 && ks_f == 4 && in1.nparts == 1 &&
-                               (size_t)c.ffn >= (size_t)RM_FFN_GRANULES;
+        const bool fused_mlp = rg.mlp && in1.nparts == 1;
         if (fused_mlp) {
             if (tm.on(0)) {
                 RowsMlpArgs a{};
@@ -1103,7 +1123,8 @@ ma_sample_cfg resolve_sample_cfg(ma_engine* e, const ma_sample_cfg* sc) {
         r.max_new_tokens = e->maxnew;
     }
     if (r.check_every <= 0) r.check_every = 64;
-    if (r.logits_first_step < 0 || r.logits_first_step >= r.max_new_tokens) throw MaError(MA_ERR_INVALID, "logits_first_step must be in [0, max_new_tokens)");
+    if (!r.logits_out) r.logits_first_step = 0;                          // (no effect without logits_out: whatever the caller left there is ignored)
+    else if (r.logits_first_step < 0 || r.logits_first_step >= r.max_new_tokens) throw MaError(MA_ERR_INVALID, "logits_first_step must be in [0, max_new_tokens) when logits_out is set");
     if (r.do_sample && (r.top_k < 1 || r.top_k > PICK_KMAX)) throw MaError(MA_ERR_INVALID, "top_k must be in [1,64]");
     if (r.do_sample && !(r.top_p > 0.f && r.top_p <= 1.f)) throw MaError(MA_ERR_INVALID, "top_p must be in (0,1]");
     return r;
@@ -1518,10 +1539,16 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_pair") { e->opt_attn_pair = (int)value; drop_graphs(e); }
         else if (n == "fuse_rows_attn") { e->opt_fuse_rows_attn = value ? 1 : 0; drop_graphs(e); }
         else if (n == "fuse_rows_mlp") { e->opt_fuse_rows_mlp = value ? 1 : 0; drop_graphs(e); }
-        else if (n == "rows_attn_early") { if (value < 0 || value > 6) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 6"); e->opt_rows_attn_early = (int)value; drop_graphs(e); }
+        else if (n == "rows_attn_early") {
+            if (value < 0 || value > 6) throw MaError(MA_ERR_INVALID, "rows_attn_early: 0 .. 6");
+#ifndef MA_EXPERIMENTAL
+            if (value != 3 && value != 5 && value != 6) throw MaError(MA_ERR_STATE, "rows_attn_early: placements 0, 1, 2 and 4 need a library built with MA_EXPERIMENTAL=1 (measured, not kept)");
+#endif
+            e->opt_rows_attn_early = (int)value; drop_graphs(e);
+        }
         else if (n == "rows_mlp_ln2") { e->opt_rows_mlp_ln2 = value ? 1 : 0; drop_graphs(e); }
         else if (n == "rows_mlp_prefetch") { if (value < 0 || value > 9) throw MaError(MA_ERR_INVALID, "rows_mlp_prefetch: 0 off, 1 / 2 rounds, 8 weights only, 9 half a round"); e->opt_rows_mlp_prefetch = (int)value; drop_graphs(e); }
-        else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; }
+        else if (n == "decode_groups") { if (value < 1 || value > 16) throw MaError(MA_ERR_INVALID, "decode_groups: 1 .. 16"); e->opt_decode_groups = (int)value; drop_graphs(e); }      // (the captured steps embed the fused 8-row launches, which rows_gate refuses beside a second row group)
         else if (n == "mfma_fold_fc1_max") { e->opt_mfma_fold_fc1_max = (int)value; drop_graphs(e); }
         else if (n == "mfma_fold_qkv_max") { e->opt_mfma_fold_qkv_max = (int)value; drop_graphs(e); }
         else if (n == "oproj_fc1_sweep_waves") { e->opt_oproj_fc1_sweep_waves = (int)value; drop_graphs(e); }
@@ -1536,7 +1563,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
-        else if (n == "gemm256") gemm256_enabled() = value ? 1 : 0;
+        else if (n == "gemm256") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "gemm256: 0 (128-row tiles), 1 (one tile per workgroup) or 2 (1 + the persistent form)"); gemm256_enabled() = (int)value; }
         else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
         else if (n == "gemm_variant") {
 #ifndef MA_EXPERIMENTAL
@@ -1606,8 +1633,11 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "mfma_chunks") *value = gemm_dec_chunks();
         else if (n == "mfma_fc2_ksplit") *value = e->opt_mfma_fc2_ksplit;
         else if (n == "attn_pair") *value = e->opt_attn_pair;
-        else if (n == "fuse_rows_attn") *value = e->opt_fuse_rows_attn && e->rows_ok && e->chain_resident;      // as the engine will apply it at 8 rows
-        else if (n == "fuse_rows_mlp") *value = e->opt_fuse_rows_mlp && e->rows_ok && e->chain_resident;
+        else if (n == "fuse_rows_attn" || n == "fuse_rows_mlp") {      // as the engine will apply it at 8 rows: the very gates of enqueue_layers_mfma
+            const RowsGates rg = rows_gates(e, RA_ROWS, -1);
+            // (the first half also needs its LayerNorm 2 folded in, or left by the previous layer's second half)
+            *value = n == "fuse_rows_mlp" ? rg.mlp : (rg.attn && (rg.fold || (rg.mlp && e->opt_rows_mlp_ln2)));
+        }
         else if (n == "rows_attn_early") *value = e->opt_rows_attn_early;
         else if (n == "rows_mlp_ln2") *value = e->opt_rows_mlp_ln2;
         else if (n == "rows_mlp_prefetch") *value = e->opt_rows_mlp_prefetch;

@@ -46,7 +46,10 @@ template <int N> __device__ __forceinline__ void g256_wait_vm() { asm volatile("
 // the n-fastest list.
 // ACT: the activation is a template parameter here (128 accumulators x an inlined erf would otherwise sit in every instantiation)
 // ABL (scripts/ubench_gemm256.hip only; 0 in the library): ablation bits -- 1 no LDS-DMA in the loop, 2 no ds_reads, 4 no MFMAs, 8 no stores
-template <typename HT, int ACT, int ABL = 0>
+// EV (scripts/ubench_gemm256_epi.hip only; G256_EV in the library): epilogue form bits -- 2 the straight-line form of whole tiles (all LDS reads /
+// residual loads of a pass issued first, then the stores); (bit 1, the hardware 16-bit conversion, became common.hpp's f2bf / pack2)
+constexpr int G256_EV = 2;
+template <typename HT, int ACT, int ABL = 0, int EV = G256_EV>
 MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char g256_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
@@ -201,6 +204,9 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
             bias4[b][i] = b4;
         }
     const int nw0 = bn + wn * 64;                                    // first column of this wave's sub-tile
+    // whole tiles with plain row addressing take the straight-line form: every LDS read (and residual load) of a pass is issued before the first
+    // store, so a pass costs one LDS / memory round trip instead of one per store (the guarded loop below waits for each chunk in turn)
+    const bool whole = (EV & 2) && bm + 256 <= g.M && bn + 256 <= g.N && g.cmap.grp == 0 && g.r_mod == 0;
     if (g.C == nullptr) {
         // 16-bit output only: patch rows of 128 B (64 elements), chunk = 8 elements
 #pragma unroll
@@ -220,6 +226,14 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int r8 = lane >> 3, c = lane & 7, ncol = nw0 + c * 8;
         if constexpr (!(ABL & 8)) {
+        if (whole) {
+            u32x4 q[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) { const int row = it * 8 + r8; q[it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((c ^ (row & 7)) * 16)); }
+            bf16_t* dst = g.Cb + (size_t)(bm + wm * 128 + r8) * g.ldcb + ncol;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) *reinterpret_cast<u32x4*>(dst + (size_t)(it * 8) * g.ldcb) = q[it];
+        } else {
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int row = it * 8 + r8, m = bm + wm * 128 + row;
@@ -227,12 +241,25 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
             const u32x4 q = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
             bf16_t* dst = g.Cb + g.cmap(m) * g.ldcb + ncol;
             if (ncol + 7 < g.N) *reinterpret_cast<u32x4*>(dst) = q;
-            else { const bf16_t* e = reinterpret_cast<const bf16_t*>(&q); for (int r = 0; r < 8 && ncol + r < g.N; ++r) dst[r] = e[r]; }
+            else {                                                   // ragged right edge: element stores straight from the registers (no address of q taken)
+                const unsigned qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (ncol + r < g.N) dst[r] = (bf16_t)(qw[r >> 1] >> ((r & 1) * 16));
+            }
+        }
         }
         }
     } else {
         // fp32 output (+ residual, + optional 16-bit copy): 64 rows at a time, patch rows of 256 B (64 floats), chunk = 4 floats
         const int r4 = lane >> 4, c = lane & 15, ncol = nw0 + c * 4;
+        // whole tiles: four passes of 32 rows (8 chunks per lane); the residual rows of pass p + 1 are requested before the stores of pass p go out
+        f32x4 rv[8];
+        auto load_res = [&](int pass) {
+            const float* rp = g.R + (size_t)(bm + wm * 128 + pass * 32 + r4) * g.ldr + ncol;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rv[it] = *reinterpret_cast<const f32x4*>(rp + (size_t)(it * 4) * g.ldr);
+        };
+        if (whole && g.R) load_res(0);
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -249,6 +276,29 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
                     }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (!(ABL & 8)) {
+            if (whole) {
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    const int pass = a * 2 + hb;
+                    f32x4 v[8];
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) { const int row = hb * 32 + it * 4 + r4; v[it] = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ (row & 15)) * 16)); }
+                    if (g.R) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) { v[it].x += rv[it].x; v[it].y += rv[it].y; v[it].z += rv[it].z; v[it].w += rv[it].w; }
+                        if (pass < 3) load_res(pass + 1);
+                    }
+                    const size_t m0 = (size_t)(bm + wm * 128 + pass * 32 + r4);
+                    float* cp = g.C + m0 * g.ldc + ncol;
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) *reinterpret_cast<f32x4*>(cp + (size_t)(it * 4) * g.ldc) = v[it];
+                    if (g.Cb) {
+                        bf16_t* cb = g.Cb + m0 * g.ldcb + ncol;
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x2*>(cb + (size_t)(it * 4) * g.ldcb) = pack4<HT>(v[it]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int row = it * 4 + r4, m = bm + wm * 128 + a * 64 + row;
@@ -270,10 +320,253 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
                 }
             }
             }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the patch is re-written for the second half
         }
     }
     if (trace && tid == 0) trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---- the persistent form (round 6): one workgroup per CU walks the tile list --------------------------------------------------------------------
+// What the one-tile kernel above leaves uncovered at K = 768 .. 1024 is fixed cost per tile, not the K-loop: ~2.5 us until the first K-tile has
+// landed, the dispatch of a fresh 512-thread / 128-KB workgroup per tile, and the epilogue's stores, which the block can only END behind
+// (profiles/r06_ubench_gemm256_epi.txt).  Here a workgroup keeps its CU for the whole launch (grid = CUs, tile = blockIdx + i * grid):
+//   * the FIRST TWO K-tiles of the next tile are requested right after the K-loop's last barrier, BEFORE the epilogue of the tile just computed:
+//     they land under the epilogue, and the next K-loop starts without a fill;
+//   * the epilogue goes through a 4-KB patch per wave in the LDS the operand buffers do not use (128 + 8 x 4 = 160 KB, the whole LDS of a CU) --
+//     four passes of 32 rows: 8 ds_write_b64, 4 ds_read_b128, 4 global_store_dwordx4 -- and its 16 stores are never waited for: they drain
+//     under the next tile's first K-tiles.  The vector-memory counter completes in order, so the first wait that names a load younger than the
+//     stores (P3 of K-tile 1) is also the point by which the stores must have left: ~2 K-tiles after they were issued;
+//   * the bias cannot be loaded by ordinary loads without draining that queue (hipcc's own wait for a VGPR load counts only what it issued:
+//     beside 16 LDS-DMA requests it would wait for nearly all of them): the wave's 64 bias values travel by ONE 4-byte LDS-DMA into the head of
+//     its patch, requested after the previous epilogue, covered by the K-loop's closing vmcnt(0), read back by ds_read.
+// Counted waits (vector-memory operations per wave, oldest first, when a tile starts): 16 LDS-DMA of K-tiles 0 / 1 | 16 epilogue stores | 1 bias DMA
+// -> `vmcnt(17)` = both K-tiles landed (first tile: no stores yet -> vmcnt(1)); K-tile 0 stages nothing at P0 / P1 (already there) and waits for
+// nothing; from K-tile 1 on the loop is the one above.  The count of 16 stores is load-bearing: tests/test_gemm256p_isa.py counts them in the ISA.
+// Whole tiles only, 16-bit output only (launch_gemm_dense sends everything else to the one-tile kernel): M, N multiples of 256, plain row addressing.
+// Same MFMA order per output as every other tile of this file: bit-identical results.
+constexpr int G256P_PATCH = 4096;
+constexpr int G256P_LDS = G256_LDS + 8 * G256P_PATCH;
+
+MA_NO_ASAN __device__ __forceinline__ void gt_glds4(const void* gsrc, unsigned lds_dst) {       // 4 bytes per lane: LDS[dst + 4 lane] <- *gsrc
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+
+template <typename HT, int ACT, int ABL = 0>
+MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char g256_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
+    const int tiles = nty * ntx;
+    const unsigned lds0 = (unsigned)(size_t)g256_smem;
+    const int nk = g.K >> 6;
+    // tile list as in gemm256_kernel: XCD i works on the i-th eighth of the list (grid is a multiple of 8: a workgroup stays on its XCD's eighth),
+    // inside it column panels of four n-tiles, m fastest
+    auto tile_origin = [&](int t, int& bm, int& bn) {
+        const int xcd = t & 7, i = t >> 3, lo = tiles >> 3, rem = tiles & 7;
+        t = xcd * lo + min(xcd, rem) + i;
+        const int fullp = ntx >> 2, tailw = ntx & 3, cut = fullp * 4 * nty;
+        int tile_y, tile_x;
+        if (t < cut) { const int p = t / (4 * nty), r = t - p * 4 * nty; tile_y = r >> 2; tile_x = p * 4 + (r & 3); }
+        else { const int r = t - cut; tile_y = r / tailw; tile_x = fullp * 4 + r - tile_y * tailw; }
+        bm = tile_y * 256; bn = tile_x * 256;
+    };
+
+    const int drow = lane >> 3, dslot = lane & 7;
+    const bf16_t* xsrc[2][2]; const bf16_t* wsrc[2][2];             // [piece s][instruction i]: source of this lane, K-tile 0 of the tile being staged
+    auto set_src = [&](int bm, int bn) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pr = (w + 8 * i) * 8 + drow;               // piece row
+                const int sw = (dslot ^ (pr & 7)) * 8;               // swizzled 16-byte chunk of the source row
+                const int m = bm + (pr >> 6) * 128 + s * 64 + (pr & 63);
+                const int n = bn + (pr >> 5) * 64 + s * 32 + (pr & 31);
+                xsrc[s][i] = g.A + (size_t)m * g.lda + sw;
+                wsrc[s][i] = g.W + (size_t)n * g.K + sw;
+            }
+    };
+    auto stage_x = [&](int s, int kt) {
+        if constexpr (ABL & 1) { if (kt > 1) return; }
+        const unsigned dst = lds0 + (unsigned)(kt & 1) * (4u * G256_PIECE) + (unsigned)s * G256_PIECE + (unsigned)w * 1024u;
+        gt_glds16(xsrc[s][0] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst));
+        gt_glds16(xsrc[s][1] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst + 8192u));
+    };
+    auto stage_w = [&](int s, int kt) {
+        if constexpr (ABL & 1) { if (kt > 1) return; }
+        const unsigned dst = lds0 + (unsigned)(kt & 1) * (4u * G256_PIECE) + (unsigned)(2 + s) * G256_PIECE + (unsigned)w * 1024u;
+        gt_glds16(wsrc[s][0] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst));
+        gt_glds16(wsrc[s][1] + (size_t)kt * 64, __builtin_amdgcn_readfirstlane(dst + 8192u));
+    };
+    auto stage_first_two = [&]() {                                   // 16 requests per wave, the order the K-loop would have issued them in
+        stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
+        stage_x(0, 1); stage_w(1, 1); stage_x(1, 1); stage_w(0, 1);
+    };
+    char* patch = g256_smem + G256_LDS + w * G256P_PATCH;
+    // ALWAYS one request (the counted waits assume it): without a bias any readable word will do, the values are then not used
+    auto stage_bias = [&](int bn) {
+        const float* src = g.bias ? g.bias + bn + wn * 64 + lane : reinterpret_cast<const float*>(g.W) + lane;
+        gt_glds4(src, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)G256_LDS + (unsigned)w * (unsigned)G256P_PATCH));
+    };
+
+    const int fr = lane & 15, kg = lane >> 4;
+    int xoff[4][2], woff[2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const int pr = wm * 64 + j * 16 + fr; xoff[j][ks] = pr * 128 + (((ks * 4 + kg) ^ (pr & 7)) * 16); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const int pr = wn * 32 + i * 16 + fr; woff[i][ks] = pr * 128 + (((ks * 4 + kg) ^ (pr & 7)) * 16); }
+
+    f32x4 acc[2][2][2][4];                                           // [x sub][w sub][n tile i][m tile j]
+    u32x4 xf[4][2], wf[2][2];
+    auto read_x = [&](int s, int kt) {
+        if constexpr (ABL & 2) { if (kt > 0) return; }
+        const char* base = g256_smem + (kt & 1) * (4 * G256_PIECE) + s * G256_PIECE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[j][ks] = *reinterpret_cast<const u32x4*>(base + xoff[j][ks]);
+    };
+    auto read_w = [&](int s, int kt) {
+        if constexpr (ABL & 2) { if (kt > 0) return; }
+        const char* base = g256_smem + (kt & 1) * (4 * G256_PIECE) + (2 + s) * G256_PIECE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[i][ks] = *reinterpret_cast<const u32x4*>(base + woff[i][ks]);
+    };
+#define G256_COMPUTE(a, b)                                                                                       \
+    do {                                                                                                         \
+        __builtin_amdgcn_s_barrier();                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        if (!(ABL & 4) || kt == 0)                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+                    acc[a][b][i][j] = H16<HT>::mfma16(wf[i][ks], xf[j][ks], acc[a][b][i][j]);                    \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                            \
+    } while (0)
+
+    int tl = blockIdx.x;                                             // (grid <= tiles: every workgroup has a first tile)
+    int bm, bn;
+    tile_origin(tl, bm, bn);
+    set_src(bm, bn);
+    stage_first_two();
+    stage_bias(bn);
+    bool first = true;
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // both K-tiles of this tile have landed (younger: the previous tile's 16 stores and the bias request; first tile: the bias request)
+        if (first) g256_wait_vm<1>(); else g256_wait_vm<17>();
+        if (trace && tid == 0) trace[(size_t)tl * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();                   // the second wave group runs one barrier behind the first
+
+        for (int kt = 0; kt < nk; ++kt) {
+            // P0
+            read_w(0, kt); __builtin_amdgcn_sched_barrier(0); read_x(0, kt);
+            if (kt >= 1 && kt + 1 < nk) stage_x(1, kt + 1);
+            G256_COMPUTE(0, 0);
+            // P1
+            read_w(1, kt);
+            if (kt >= 1 && kt + 1 < nk) stage_w(0, kt + 1);
+            G256_COMPUTE(0, 1);
+            // P2
+            read_x(1, kt);
+            if (kt + 2 < nk) stage_x(0, kt + 2);
+            G256_COMPUTE(1, 1);
+            // P3
+            read_w(0, kt);
+            if (kt + 2 < nk) { stage_w(1, kt + 2); if (kt >= 1) g256_wait_vm<4>(); }     // K-tile 1 landed before the loop
+            else g256_wait_vm<0>();                                  // (the last K-tile: also this tile's bias and, at the latest, the previous tile's stores)
+            G256_COMPUTE(1, 0);
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();                   // (the barrier the first group is ahead by): every wave has read its last operands
+        if (trace && tid == 0) trace[(size_t)tl * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+
+        // ---- next tile's first two K-tiles, then this tile's epilogue -----------------------------------------------------------------------
+        const int bm_e = bm, bn_e = bn, tl_e = tl;
+        tl += gridDim.x;
+        const bool more = tl < tiles;
+        if (more) {
+            tile_origin(tl, bm, bn);
+            set_src(bm, bn);
+            stage_first_two();
+        }
+        f32x4 bias4[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bias4[b][i] = *reinterpret_cast<const f32x4*>(patch + (b * 32 + i * 16 + kg * 4) * 4);
+                if (!g.bias) bias4[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const int r8 = lane >> 3, c = lane & 7;
+            bf16_t* dst = g.Cb + (size_t)(bm_e + wm * 128 + r8) * g.ldcb + (bn_e + wn * 64 + c * 8);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {                          // pass st: the wave's rows 32 st .. 32 st + 31
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            f32x4 v = acc[st >> 1][b][i][(st & 1) * 2 + jj];
+                            const f32x4 b4 = bias4[b][i];
+                            v.x = apply_act(v.x + b4.x, ACT); v.y = apply_act(v.y + b4.y, ACT); v.z = apply_act(v.z + b4.z, ACT); v.w = apply_act(v.w + b4.w, ACT);
+                            const int rr = jj * 16 + fr, chunk = b * 4 + i * 2 + (kg >> 1);
+                            *reinterpret_cast<u32x2*>(patch + rr * 128 + ((chunk ^ (rr & 7)) * 16) + (kg & 1) * 8) = pack4<HT>(v);
+                        }
+                u32x4 q[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { const int row = it * 8 + r8; q[it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((c ^ (row & 7)) * 16)); }
+                if constexpr (!(ABL & 8)) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(dst + (size_t)(st * 32 + it * 8) * g.ldcb) = q[it];
+                } else { asm volatile("" :: "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3])); }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the patch's last read has returned: its head may take the next bias
+        if (!more) {
+            if (trace && tid == 0) trace[(size_t)tl_e * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            break;
+        }
+        stage_bias(bn);
+        if (trace && tid == 0) trace[(size_t)tl_e * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+        first = false;
+    }
+#undef G256_COMPUTE
+}
+
+template <typename HT, int ACT>
+inline hipError_t g256p_launch(const GemmTArgs& g, int nty, int ntx, int n_cus, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<HT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS);
+        if (r != hipSuccess) return r;
+        attr = true;
+    }
+    const int grid = nty * ntx <= n_cus ? nty * ntx : n_cus & ~7;      // (several rounds: a multiple of 8, so that a workgroup stays on its XCD's part of the tile list)
+    hipLaunchKernelGGL((gemm256p_kernel<HT, ACT>), dim3(grid), dim3(512), G256P_LDS, s, g, nty, ntx, (unsigned long long*)nullptr);
+    return hipGetLastError();
 }
 
 template <typename HT, int ACT>
@@ -288,12 +581,13 @@ inline hipError_t g256_launch(const GemmTArgs& g, int nty, int ntx, hipStream_t 
     return hipGetLastError();
 }
 
-// engine option "gemm256" (default 1): A/B switch between this kernel and the 128-row tiles for the shapes it covers
-inline int& gemm256_enabled() { static int v = 1; return v; }
+// engine option "gemm256" (default 2): 0 = the 128-row tiles only; 1 = the one-tile 256 x 256 kernel for the shapes it covers; 2 = 1 + the persistent
+// form for whole-tile 16-bit-output problems
+inline int& gemm256_enabled() { static int v = 2; return v; }
 
-// The dense GEMM of the 16-bit policies.  The big tile wants WHOLE rounds of the chip (one block per CU): the matrix is cut along M into
-//   * the leading tile rows whose tiles fill the rounds to within 12 % -- all whole tile rows when that holds (M = 64 x 257: 64 rows of 4 / 12 /
-//     16 tiles = 1 / 3 / 4 rounds), else the largest count that makes exact rounds (M = 64 x 1057, N = 768: 256 of the 264 tile rows x 3 tiles);
+// The dense GEMM of the 16-bit policies.  The big tile wants rounds of the chip (one block per CU) that are reasonably full: the matrix is cut along M into
+//   * the leading tile rows whose tiles fill their rounds to 60 % or more -- all whole tile rows when that holds (M = 64 x 257: 64 rows of 4 / 12 /
+//     16 tiles = 1 / 3 / 4 rounds; M = 16 x 257, N = 3072: 192 tiles = 0.75 round), else the largest count that makes exact rounds;
 //   * the rest: a tail of <= 64 rows (M = B x 257 and B x 1057 leave 64 at B = 64) goes to the skinny matrix-core GEMM of the batched decode
 //     step (gemm_decode.hpp: 16 weight rows per block, the tail's rows as the B operand); anything larger to the tiles of gemm_tile.hpp.
 // Problems that do not give the big tile one full round (small M of batch-1 runs, N = 64 / 128 projections, K not a multiple of 64) stay on
@@ -309,7 +603,10 @@ inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s
     if (tile256_ok && gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && (long)((g.N + 255) / 256) * ((g.M + 255) / 256) < (1L << 24)) {
         const int ntx = (g.N + 255) / 256;
         const bool can_split = g.cmap.grp == 0 && g.r_mod == 0;
-        auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles >= n_cus && tiles * 100 >= rounds * n_cus * 88; };
+        // (round 6: 60 % instead of 88 % + at least one whole round.  A tile of the big kernel now runs at ~1.2 PFLOP/s per CU-round against ~0.6 for the
+        //  128-row tiles at their best, so a launch whose last -- or only -- round is 60 % full still comes out ahead: 576 tiles = 2.25 rounds 934 vs 596
+        //  TFLOP/s, 192 tiles = 0.75 round 911 vs ~450; profiles/r06_ubench_gemm256p.txt, r06_calib_library_gemm.txt)
+        auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles * 100 >= rounds * n_cus * 60; };
         int nty = 0;                                                 // tile rows on the big tile
         if (!can_split) { if (fills((long)ntx * ((g.M + 255) / 256))) nty = (g.M + 255) / 256; }      // ragged last tile row computed with clamped rows
         else if (fills((long)ntx * (g.M / 256))) nty = g.M / 256;
@@ -317,7 +614,12 @@ inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s
         if (nty > 0) {
             GemmTArgs m = g;
             m.M = can_split ? nty * 256 : g.M;
-            hipError_t r = g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s);
+            // whole tiles with 16-bit output: the persistent form (next tile's operands requested before this tile's epilogue; its 4-KB-patch epilogue is
+            // the faster one even where every workgroup has a single tile)
+            const bool persist = gemm256_enabled() >= 2 && can_split && !g.C && g.Cb && !g.R && g.N % 256 == 0 && n_cus >= 8;
+            hipError_t r = persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
+                                                                                                                             : g256p_launch<HT, ACT_NONE>(m, nty, ntx, n_cus, s))
+                                   : (g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s));
             const int rest = can_split ? g.M - nty * 256 : 0;
             if (r != hipSuccess || rest == 0) return r;
             const size_t r0 = (size_t)nty * 256;

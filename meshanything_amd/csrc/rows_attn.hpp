@@ -564,6 +564,10 @@ template <typename HT>
 inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, hipStream_t s, int early_kv = 2, int q_waves = 4) {
     if (heads != 16 || rows != RA_ROWS || !a.Wqkv || !a.Wo || !a.qkv_gran || !a.pair_gran || !a.out_gran || !a.err || !a.y1 || a.y1_stride % 4) return hipErrorInvalidValue;
     const dim3 grid(16, RA_ROWS, 2), block(512);
+    // placements: 6 (the default) and its two controls -- 5 (6 without the mask-free rounds) and 3 (the q/k/v sweep by vector loads) -- are
+    // product code; 0, 1, 2 and 4 were measured and not kept (profiles/r05_ab_rows_attn_request_placement.txt) and are compiled in with
+    // MA_EXPERIMENTAL=1 only (84 instantiations of this kernel sat in the product library)
+#ifdef MA_EXPERIMENTAL
     if (early_kv < 0 || early_kv > 6) return hipErrorInvalidValue;
 #define MA_RA(L, P, D, Q) do { if (early_kv == 2) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 2, Q, HT>), grid, block, 0, s, a); \
                                else if (early_kv == 5) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 5, Q, HT>), grid, block, 0, s, a); \
@@ -572,6 +576,12 @@ inline hipError_t launch_rows_attn(const RowsAttnArgs& a, int heads, int rows, h
                                else if (early_kv == 4) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 4, Q, HT>), grid, block, 0, s, a); \
                                else if (early_kv == 1) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 1, Q, HT>), grid, block, 0, s, a); \
                                else hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 0, Q, HT>), grid, block, 0, s, a); } while (0)
+#else
+    if (early_kv != 3 && early_kv != 5 && early_kv != 6) return hipErrorInvalidValue;
+#define MA_RA(L, P, D, Q) do { if (early_kv == 5) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 5, Q, HT>), grid, block, 0, s, a); \
+                               else if (early_kv == 6) hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 6, Q, HT>), grid, block, 0, s, a); \
+                               else hipLaunchKernelGGL((rows_attn_kernel<L, P, D, 3, Q, HT>), grid, block, 0, s, a); } while (0)
+#endif
     if (!a.ln_g) {
         if (!a.xb || !a.res || a.xb_stride % 8 || a.res_stride % 4) return hipErrorInvalidValue;
         if (q_waves == 8) MA_RA(false, 1, false, 8);

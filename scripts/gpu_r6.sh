@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round 6, GPU box: the stages named in $STAGES (space separated) on the tree as it stands; everything lands in gpurun_out/$TAG/
+#   suite   pytest -m gpu + smoke            dense   scripts/prof_dense.py (dense-phase times per batch) + its rocprof kernel stats at B = $PB
+#   calib   scripts/calib_library_gemm.py    bench   bench.py (defaults)         b8 / cfg5   bench.py --batch 8 [--faces 1600]
+#   exp     the MA_EXPERIMENTAL tests        trace8  the 8-row step's timeline
+#   gemmtests  the dense GEMM kernel tests (-s: their timing lines)    stress  scripts/stress_gemm256.py
+TAG=${TAG:-r6}; STAGES=${STAGES:-suite}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.build()" > $O/build.txt 2>&1 || { tail -20 $O/build.txt; exit 1; }
+for st in $STAGES; do
+  echo "== $st"
+  case $st in
+    suite)
+      timeout ${SUITE_TMO:-1200} python -m pytest tests -m gpu -x -q -p no:cacheprovider ${PYTEST_ARGS} 2>&1 | grep -v amdgpu.ids > $O/suite.txt; tail -6 $O/suite.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt ;;
+    exp)
+      MA_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_persist.py tests/test_gpu_rows_fused.py tests/test_gpu_rows_attn.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids > $O/suite_experimental.txt; tail -3 $O/suite_experimental.txt ;;
+    dense)
+      timeout 600 python scripts/prof_dense.py --batches ${BATCHES:-16,64} 2>&1 | grep -v amdgpu.ids > $O/dense.txt; cat $O/dense.txt
+      cd /tmp; rm -rf /tmp/prof_d
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_d -o d --output-format csv -- python $R/scripts/prof_dense.py --batches ${PB:-64} --iters 2 > $O/prof_dense_rocprof.log 2>&1
+      for f in $(find /tmp/prof_d -name "*kernel_stats*.csv"); do cp $f $O/dense_b${PB:-64}_kernel_stats.csv; done
+      head -14 $O/dense_b${PB:-64}_kernel_stats.csv | cut -c1-180; cd $R ;;
+    calib)
+      timeout 600 python scripts/calib_library_gemm.py 2>&1 | grep -v amdgpu.ids > $O/calib_library_gemm.txt; cat $O/calib_library_gemm.txt ;;
+    bench)
+      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-600 $O/bench.json; echo ;;
+    b8)
+      timeout 600 python bench.py --batch 8 --steps 2 --warmup 1 --no-cpu-baseline > $O/b8_800.json 2> $O/b8.err; cut -c1-400 $O/b8_800.json; echo ;;
+    cfg5)
+      timeout 600 python bench.py --batch 8 --faces 1600 --steps 1 --warmup 0 --no-cpu-baseline > $O/cfg5_b8_1600.json 2> $O/cfg5.err; cut -c1-400 $O/cfg5_b8_1600.json; echo ;;
+    trace8)
+      timeout 300 python scripts/trace_step.py --batch 8 --lens 300,3858,7300 --dist 2>&1 | grep -v amdgpu.ids > $O/trace_b8.txt; grep -E "len|attn |fc1 " $O/trace_b8.txt ;;
+    gemmtests)
+      timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider -k "gemm" -s 2>&1 | grep -v amdgpu.ids > $O/gemmtests.txt; grep -E "gemm256|passed|failed|Error" $O/gemmtests.txt | cut -c1-330 | tail -40 ;;
+    stress)
+      timeout 900 python scripts/stress_gemm256.py ${STRESS_N:-600} 2>&1 | grep -v amdgpu.ids > $O/stress_gemm256.txt; tail -30 $O/stress_gemm256.txt ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done

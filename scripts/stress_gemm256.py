@@ -26,7 +26,8 @@ from meshanything_amd.engine import Engine                          # noqa: E402
 
 SHAPES = [(16448, 1024, 1024, 0, True, "f32"), (16448, 3072, 1024, 0, False, "bf16"), (16448, 4096, 1024, 1, False, "bf16"),
           (16448, 1024, 4096, 0, True, "f32"), (67648, 768, 768, 2, False, "both"), (8192, 8192, 512, 0, False, "bf16"),
-          (4097, 4352, 128, 0, True, "both"), (33000, 1152, 768, 0, False, "f32"), (66000, 256, 64, 0, False, "f32")]
+          (4097, 4352, 128, 0, True, "both"), (33000, 1152, 768, 0, False, "f32"), (66000, 256, 64, 0, False, "f32"),
+          (67648, 2304, 768, 0, False, "bf16"), (16448, 3072, 768, 2, False, "bf16"), (4112, 3072, 1024, 0, False, "bf16")]
 
 
 def p(t):
@@ -38,7 +39,7 @@ def main():
     lib = _lib.load()
     print(lib.ma_version().decode(), "| MA_DEBUG =", os.environ.get("MA_DEBUG", ""), "| device", torch.cuda.get_device_name(0), flush=True)
     eng = Engine(MAConfig.tiny(dtype=DTYPE_BF16))
-    eng.set_option("gemm256", 1)
+    eng.set_option("gemm256", 2)
     main_s = torch.cuda.current_stream()
     side, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
     src = torch.empty(1 << 28, dtype=torch.uint8, device="cuda").random_(0, 255)

@@ -586,7 +586,8 @@ def test_gemm_bf16_tile(lib, h16, M, N, K, act, use_res, out, variant):
 
 @pytest.mark.parametrize("M,N,K,act,use_res,out", [(16448, 1024, 1024, 0, True, "f32"), (16448, 3072, 1024, 0, False, "bf16"), (16448, 4096, 1024, 1, False, "bf16"),
                                                    (16448, 1024, 4096, 0, True, "f32"), (67648, 768, 768, 2, False, "both"), (8192, 8192, 512, 0, False, "bf16"),
-                                                   (4097, 4352, 128, 0, True, "both"), (33000, 1152, 768, 0, False, "f32"), (66000, 256, 64, 0, False, "f32")])
+                                                   (4097, 4352, 128, 0, True, "both"), (33000, 1152, 768, 0, False, "f32"), (66000, 256, 64, 0, False, "f32"),
+          (67648, 2304, 768, 0, False, "bf16"), (16448, 3072, 768, 2, False, "bf16"), (4112, 3072, 1024, 0, False, "bf16")])
 def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
     """The 256 x 256 x 64 eight-wave tile with the staged K-loop (csrc/gemm256.hpp) at the batched dense-phase shapes -- M = 64 x 257 (65 tile
     rows: whole rounds on the big tile + the remainder on 128 x 128 tiles), M = 64 x 1057, ragged M and N edges, K = 64 (one K-tile: prologue only)
@@ -613,7 +614,7 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
     def run(Cf, Cb):
         _chk(lib, lib.ma_op_gemm_bf16(_p(A), K, _p(W), _p(bias), _p(R), N, _p(Cf), N, _p(Cb), N, M, N, K, act, _stream()))
     res = {}
-    for mode in (1, 0, 1):
+    for mode in (2, 1, 0, 2):                            # 2: + the persistent form where it applies (whole-tile 16-bit output, more than one round)
         knob.set_option("gemm256", mode)
         Cf = torch.full((M, N), float("nan")) if out in ("f32", "both") else None
         Cb = torch.zeros(M, N, dtype=h16.tdt) if out in ("bf16", "both") else None
@@ -631,8 +632,8 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
             assert float(e16.max()) < 6e-3, f"16-bit output off by {float(e16.max()):.3e}: " + where(e16 >= 6e-3)
             if Cf is not None:
                 assert torch.equal(Cb, Cf.to(h16.tdt)), "16-bit copy is not the rounded fp32 output: " + where(Cb != Cf.to(h16.tdt))
-        if mode == 1 and 1 in res:
-            for a_, b_ in zip(res[1], (Cf, Cb)):
+        if mode == 2 and 2 in res:
+            for a_, b_ in zip(res[2], (Cf, Cb)):
                 assert a_ is None or torch.equal(a_, b_), "the 256 x 256 kernel is not bit-stable from launch to launch: " + where(a_ != b_)
         res[mode] = (Cf, Cb)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -649,8 +650,10 @@ def test_gemm_256_tile(lib, h16, M, N, K, act, use_res, out):
     same_rows = M - (M % 256 if M % 256 <= 64 else 0)
     for a_, b_ in zip(res[0], res[1]):
         assert a_ is None or torch.equal(a_[:same_rows], b_[:same_rows]), "256 x 256 and 128-row tiles disagree bitwise: " + str(int((a_[:same_rows] != b_[:same_rows]).sum())) + " elements"
+    for a_, b_ in zip(res[2], res[1]):
+        assert a_ is None or torch.equal(a_, b_), "the persistent and the one-tile 256 x 256 kernels disagree bitwise: " + str(int((a_ != b_).sum())) + " elements"
     fl = 2.0 * M * N * K
-    print(f"[gemm256 {h16.name}] M {M} N {N} K {K} act {act} res {use_res} out {out}: 256x256 {res[('us', 1)]:.1f} us = {fl / res[('us', 1)] * 1e-6:.1f} TFLOP/s | "
-          f"128-row tiles {res[('us', 0)]:.1f} us = {fl / res[('us', 0)] * 1e-6:.1f} TFLOP/s | ratio {res[('us', 0)] / res[('us', 1)]:.2f}x")
-    knob.set_option("gemm256", 1)
+    print(f"[gemm256 {h16.name}] M {M} N {N} K {K} act {act} res {use_res} out {out}: default (persistent where it applies) {res[('us', 2)]:.1f} us = {fl / res[('us', 2)] * 1e-6:.1f} TFLOP/s | "
+          f"one tile per workgroup {res[('us', 1)]:.1f} us = {fl / res[('us', 1)] * 1e-6:.1f} | 128-row tiles {res[('us', 0)]:.1f} us = {fl / res[('us', 0)] * 1e-6:.1f} | ratio {res[('us', 0)] / res[('us', 2)]:.2f}x")
+    knob.set_option("gemm256", 2)
     knob.close()

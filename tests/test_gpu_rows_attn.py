@@ -101,7 +101,8 @@ def test_request_placements_and_the_scalar_sweep_are_bitwise_the_same(eng8):
     n = 600
     try:
         ref = None
-        for early in (6, 0, 1, 2, 3, 4, 5):
+        # (0, 1, 2, 4 -- measured, not kept -- exist in MA_EXPERIMENTAL=1 builds only)
+        for early in ((6, 0, 1, 2, 3, 4, 5) if eng8.get_option("experimental") else (6, 3, 5)):
             eng8.set_option("rows_attn_early", early)
             t, _, g = eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True, return_logits=True)
             if ref is None:
