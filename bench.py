@@ -31,6 +31,9 @@ from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32  
 from meshanything_amd.checkpoint import synthetic_state_dict          # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+# health counters of the fused decode launches (ma_engine_get_option): generations that fell back to the launch chain, sweeps that gave up, the error word of
+# the last fall-back, scalar sweeps a vector look had to finish (rows_attn.hpp), long-lived blocks
+HEALTH_KEYS = ("chain_resident", "chain_fallbacks", "xchg_timeouts", "xchg_last_code", "scalar_sweep_rescues", "slow_blocks", "slow_block_max_us")
 
 
 def synth_cloud(seed: int, n: int) -> np.ndarray:
@@ -306,7 +309,7 @@ def main():
     tokens_distinct = [len(set(r.tolist())) for r in out["tokens"].cpu()]
     # health of the fused decode launches over everything this engine ran so far (a generation that lost them was re-run on the
     # five-launch chain: correct, slower, and visible here)
-    health = {k: eng.get_option(k) for k in ("chain_resident", "chain_fallbacks", "xchg_timeouts", "slow_blocks", "slow_block_max_us")}
+    health = {k: eng.get_option(k) for k in HEALTH_KEYS}
     # encoder activations of shape 0 (mouse.npy) against the reference's own perceiver (tests/golden/full.npz; the encoder weights of
     # init="diverse" are the default ones): the north star's 1e-5
     enc_err = None
@@ -393,12 +396,13 @@ def main():
                     "decode_step_ms_graph": round(prof["step_ms_graph"], 4), "decode_step_ms_eager": round(prof["step_ms_eager"], 4),
                     "decode_step_GBps_at_mid_context": round(step_bytes / (step_ms * 1e-3) / 1e9, 1),
                     "decode_step_frac_of_peak": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        health_after = {k: eng.get_option(k) for k in ("chain_resident", "chain_fallbacks", "xchg_timeouts", "slow_blocks", "slow_block_max_us")}
+        health_after = {k: eng.get_option(k) for k in HEALTH_KEYS}
         peaks = measured_peaks(eng)
         cpu = None
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             cpu = cpu_baseline(cfg, sd, torch.from_numpy(pc[:1]))
         batched = None
+        batch8_generation = None
         dense = None
         fp32_exact = None
         fp16_policy = None
@@ -417,6 +421,22 @@ def main():
                 byts = wbytes + Bb * kv_bytes_per_step(cfg_b, mid, 2)
                 batched.append({"batch": Bb, "kv_len": mid, "decode_step_ms": round(sb, 4), "face_tokens_per_s": round(Bb / (sb * 1e-3), 1),
                                 "GBps": round(byts / (sb * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(byts / (sb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            # ... and ONE whole generation of 8 shapes stepping together (the per-GPU share of the metric's "batch = 8 x N"): 7202 steps, cache to the end
+            x8 = torch.from_numpy(np.stack([pc[0]] + [normalize_pc(synth_cloud(j, cfg_b.n_points)) for j in range(1, 8)])).cuda()
+            _, prefix8 = eng_b.encode(x8)
+            eng_b.generate(prefix8, suppress_eos=True, max_new_tokens=64)          # warm: graph capture for 8 rows
+            h8 = {k: eng_b.get_option(k) for k in HEALTH_KEYS}
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            t8, _ = eng_b.generate(prefix8, suppress_eos=True)
+            torch.cuda.synchronize()
+            t_8 = time.perf_counter() - t1
+            assert tuple(t8.shape) == (8, cfg_b.max_new_tokens)
+            batch8_generation = {"batch": 8, "tokens": 8 * cfg_b.max_new_tokens, "seconds": round(t_8, 3), "face_tokens_per_s": round(8 * cfg_b.max_new_tokens / t_8, 1),
+                                 "sec_per_mesh": round(t_8 / 8, 4), "ms_per_step": round(t_8 / cfg_b.max_new_tokens * 1e3, 4),
+                                 "fused_rows_attn": int(eng_b.get_option("fuse_rows_attn")), "fused_rows_mlp": int(eng_b.get_option("fuse_rows_mlp")),
+                                 "fused_launch_health_before": h8, "fused_launch_health_after": {k: eng_b.get_option(k) for k in HEALTH_KEYS},
+                                 "note": "ma_generate only (prefill + 7202 decode steps of 8 rows, eos suppressed), one warm generation, wall clock around the call"}
             dense = dense_phase_table(eng_b, cfg_b)
             eng_b.close()
             torch.cuda.empty_cache()
@@ -459,7 +479,7 @@ def main():
             "config": {"workload": pl["workload"],
                        "global_batch": pl["global_batch"], "tokens_per_mesh": cfg.max_new_tokens, "parallelism": pl["parallelism"],
                        "weights": "seeded random init in the reference key layout (no checkpoint available offline), init=diverse: checkpoint.py"},
-            "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "dense_phases": dense, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
+            "sec_per_mesh": round(dt / args.steps / args.batch, 4), "batched_decode_steps": batched, "batch8_generation": batch8_generation, "dense_phases": dense, "phases_ms": {k: round(v, 3) for k, v in phases.items()},
             "weights_load_s": round(t_load, 2), "fp32_exact": fp32_exact, "fp16_policy": fp16_policy, "roofline": roofline, "cpu_baseline": cpu,
             "tokens_distinct": tokens_distinct, "encoder_max_abs_err": enc_err, "fused_launch_health": {"timed_region": health, "after_profiling": health_after},
             "measured_peaks": peaks,

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
                 if (__all((unsigned)(vo >> 32) == epoch && (unsigned)(vm >> 32) == epoch)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, err)) {
-                    if (lane == 0) xchg_raise(err, ATTN_ERR_PAIR);
+                    if (lane == 0) xchg_raise(err, ATTN_ERR_PAIR, spins);
                     vo = 0; vm = 0;
                     break;
                 }

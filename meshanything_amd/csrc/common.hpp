@@ -293,9 +293,16 @@ __device__ __forceinline__ bool xchg_expired(unsigned& spins, u64 t0, const unsi
 // a sweep gave up: raise the bit in the engine's error word (err[0]; read and cleared by the host after the first step and after every
 // burst) and count the event in err[1], which is never cleared -- the total shows in ma_engine_get_option("xchg_timeouts") and in the
 // bench line, so a run that lost its fused launches for a while cannot look like a clean one
-__device__ __forceinline__ void xchg_raise(unsigned* err, unsigned code) {
+// The FIRST give-up since the counters were last read out also leaves who it was (round 6; the one fall-back of round 5 could not be placed):
+// err[5] = 0x80000000 | code, err[6] = blockIdx.x | y << 8 | z << 16 | wave << 24, err[7] = polls made; ma_engine_get_option("xchg_first_giveup_*").
+__device__ __forceinline__ void xchg_raise(unsigned* err, unsigned code, unsigned spins = 0) {
     __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned expect = 0;
+    if (__hip_atomic_compare_exchange_strong(err + 5, &expect, 0x80000000u | code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(err + 6, (blockIdx.x & 255u) | ((blockIdx.y & 255u) << 8) | ((blockIdx.z & 255u) << 16) | ((threadIdx.x >> 6) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(err + 7, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // diagnostics of the fused launches (a 20-30 ms dispatch per profiled run that is NOT a sweep time-out): a sweep that

@@ -196,4 +196,24 @@ __global__ void kv_fill2_kernel(const AT* __restrict__ src, int ld, int koff, in
     }
 }
 
+// the same for the rows [r_begin, r_end) of the STACKED tensor (row r = sample r / T, position r % T): the rows whose K / V the q|k|v GEMM did not
+// write into the planes itself (gemm256.hpp, GemmTArgs::kv_*: the 64-row tail behind the 256-row tiles; everything when that kernel did not run)
+template <typename AT, typename KT>
+__global__ void kv_fill_rows_kernel(const AT* __restrict__ src, int ld, int koff, int voff, int r_begin, int r_end, int T, int H, int max_seq, KT* __restrict__ kc,
+                                    KT* __restrict__ vc, size_t kv_row_stride) {
+    constexpr int V = (sizeof(AT) == 2 && sizeof(KT) == 2) ? 8 : 1;      // elements per thread
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = H * 64 / V;
+    if (idx >= (long)(r_end - r_begin) * per_row) return;
+    const int r = r_begin + (int)(idx / per_row), e = (int)(idx % per_row) * V, h = e >> 6, d = e & 63;
+    const int b = r / T, pos = r - b * T;
+    const size_t dst = (size_t)b * kv_row_stride + ((size_t)h * max_seq + pos) * 64 + d;
+    const AT* sp = src + (size_t)r * ld + h * 64 + d;
+    if constexpr (V == 8) {
+        *reinterpret_cast<u32x4*>(kc + dst) = *reinterpret_cast<const u32x4*>(sp + koff);
+        *reinterpret_cast<u32x4*>(vc + dst) = *reinterpret_cast<const u32x4*>(sp + voff);
+    } else if constexpr (sizeof(AT) == sizeof(KT)) { kc[dst] = sp[koff]; vc[dst] = sp[voff]; }
+    else { store_kv_elem<KT>(kc + dst, (float)sp[koff]); store_kv_elem<KT>(vc + dst, (float)sp[voff]); }
+}
+
 }  // namespace ma

@@ -196,6 +196,7 @@ struct ma_engine {
     unsigned long long* d_attn_pair_gran = nullptr;      // [max_batch][heads][ATTN_PAIR_GRANULES]: hand-over of the two-block final-form attention
     int opt_fuse_rows_attn = 1;      // matrix-core decode path at 8 rows: LayerNorm + q/k/v + attention + out_proj in ONE launch (rows_attn.hpp)
     bool rows_ok = false;            // the two 8-row launches (256 blocks of 512 threads each) can be resident all at once on this device
+    int opt_qkv_to_cache = 1;        // prefill (16-bit policies): the q|k|v GEMM writes K / V into the cache planes itself where it can (gemm256.hpp KV form); 0: always by kv_fill_rows_kernel (A/B)
     int opt_rows_attn_early = 6;     // rows_attn.hpp: when the first cache rounds are requested (A/B, see the kernel): 5 = the q/k/v sweep by scalar loads (waves 0 .. 3), two rounds by the waves 4 .. 7 meanwhile; 6 = 5 + rounds wholly below the newest position run without masks; 3 = one round behind the q/k/v MFMAs, sweep by vector loads
     int opt_rows_mlp_prefetch = 0;   // rows_mlp.hpp step F (measured, not kept: 0 = off): the next layer's first operands pulled into L2 by the blocks that idle during step E -- 1 | 2 rounds, 8 = weights only, 9 = half a round
     unsigned* d_pf_sink = nullptr;
@@ -261,8 +262,11 @@ struct GemmOut {                       // exactly one of: fp32 stream output | a
     float* c32 = nullptr; void* act = nullptr; int ld = 0; RowMap map{0, 0, 0};
 };
 // C = act(A . W^T + bias) + R, A an activation tensor (M, lda).  r_mod > 0: the residual row is m % r_mod.
+// kv (optional, 16-bit phases): the K / V columns of a fused q|k|v projection may go straight to these KV-cache planes (GemmTArgs::kv_*);
+// kv->rows_done = the leading rows for which they did
+struct KvDst { void* k = nullptr; void* v = nullptr; size_t row_stride = 0; int max_seq = 0, T = 0, col0 = 0; int rows_done = 0; };
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr, GemmOut out,
-          int M, int act, int r_mod = 0) {
+          int M, int act, int r_mod = 0, KvDst* kv = nullptr) {
     const Entry& en = e->L.get(w);
     const float* bias = bias_name ? e->PF(bias_name) : nullptr;
     hipError_t r;
@@ -272,7 +276,8 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
         t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
-        r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s));
+        if (kv) { t.kv_k = reinterpret_cast<bf16_t*>(kv->k); t.kv_v = reinterpret_cast<bf16_t*>(kv->v); t.kv_row_stride = kv->row_stride; t.kv_max_seq = kv->max_seq; t.kv_T = kv->T; t.kv_col0 = kv->col0; }
+        r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s, kv ? &kv->rows_done : nullptr));
     } else {
         GemmArgs g{};
         g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
@@ -283,8 +288,8 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, "gemm launch failed for " + w + ": " + hipGetErrorString(r));
 }
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr, GemmOut out, int M,
-          int act, int r_mod = 0) {
-    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod);
+          int act, int r_mod = 0, KvDst* kv = nullptr) {
+    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod, kv);
 }
 GemmOut to32(float* c, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.c32 = c; o.ld = ld; o.map = m; return o; }
 GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = a; o.ld = ld; o.map = m; return o; }
@@ -1066,15 +1071,28 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = DEC + "layers." + std::to_string(l) + ".";
-        gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE);
-        const int n = T * c.heads * 64;
-        if (e->bf16) hipLaunchKernelGGL((kv_fill2_kernel<bf16_t, bf16_t>), dim3(ceil_div(n / 8, 256), B), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, T, c.heads,
-                                        e->maxseq, reinterpret_cast<bf16_t*>(e->kplane(row0, l)), reinterpret_cast<bf16_t*>(e->vplane(row0, l)), kv_row_elems);      // a copy of 16-bit words: either format
-        else hipLaunchKernelGGL((kv_fill2_kernel<float, float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const float*>(qkv), 3 * H, H, 2 * H, T, c.heads, e->maxseq,
-                                reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
-        HIP_CHECK(hipGetLastError());
-        attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
-                  (size_t)T * 3 * H, (size_t)T * H);
+        if (e->bf16) {
+            // 16-bit policies: the K / V columns of the rows on the persistent 256 x 256 tiles go straight into the cache planes (gemm256.hpp, KV form);
+            // the rows behind them (the 64-row tail of M = B x 257; every row when another kernel took the GEMM) are copied from the q|k|v tensor.
+            // Attention then reads K, and the V^T packing V, from the planes: the cache IS the prefill's K / V operand.
+            KvDst kv; kv.k = e->kplane(row0, l); kv.v = e->vplane(row0, l); kv.row_stride = kv_row_elems; kv.max_seq = e->maxseq; kv.T = T; kv.col0 = H;
+            gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE, 0, e->opt_qkv_to_cache ? &kv : nullptr);
+            if (kv.rows_done < M) {
+                const long n = (long)(M - kv.rows_done) * c.heads * 8;
+                hipLaunchKernelGGL((kv_fill_rows_kernel<bf16_t, bf16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, kv.rows_done, M, T,
+                                   c.heads, e->maxseq, reinterpret_cast<bf16_t*>(kv.k), reinterpret_cast<bf16_t*>(kv.v), kv_row_elems);      // a copy of 16-bit words: either format
+                HIP_CHECK(hipGetLastError());
+            }
+            attention(e, s, qkv, 3 * H, 64, kv.k, 64, e->maxseq * 64, kv.v, 64, e->maxseq * 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, kv_row_elems, kv_row_elems, (size_t)T * H);
+        } else {
+            gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE);
+            const int n = T * c.heads * 64;
+            hipLaunchKernelGGL((kv_fill2_kernel<float, float>), dim3(ceil_div(n, 256), B), dim3(256), 0, s, reinterpret_cast<const float*>(qkv), 3 * H, H, 2 * H, T, c.heads, e->maxseq,
+                               reinterpret_cast<float*>(e->kplane(row0, l)), reinterpret_cast<float*>(e->vplane(row0, l)), kv_row_elems);
+            HIP_CHECK(hipGetLastError());
+            attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
+                      (size_t)T * 3 * H, (size_t)T * H);
+        }
         gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, to32(y, H), M, ACT_NONE);
         lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, hb, H, M, H);
         gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU);
@@ -1563,6 +1581,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "fuse_layer") { e->opt_fuse_layer = (int)value; drop_graphs(e); }
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
+        else if (n == "qkv_to_cache") e->opt_qkv_to_cache = value ? 1 : 0;
         else if (n == "gemm256") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "gemm256: 0 (128-row tiles), 1 (one tile per workgroup) or 2 (1 + the persistent form)"); gemm256_enabled() = (int)value; }
         else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
         else if (n == "gemm_variant") {
@@ -1614,13 +1633,15 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "chain_resident") *value = e->chain_resident ? 1 : 0;
         else if (n == "chain_fallbacks") *value = e->chain_fallbacks;
         else if (n == "xchg_last_code") *value = e->xchg_last_code;
-        else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us" || n == "scalar_sweep_rescues") {
+        else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us" || n == "scalar_sweep_rescues" || n == "xchg_first_giveup_code" ||
+                 n == "xchg_first_giveup_block" || n == "xchg_first_giveup_polls") {
             // device counters of the fused launches, never cleared: sweeps that ever gave up | blocks that lived > 1 ms | the longest of them |
-            // scalar sweeps that a vector look had to finish
-            unsigned v[5] = {0, 0, 0, 0, 0};
+            // scalar sweeps that a vector look had to finish | the first sweep that ever gave up: its error bit, blockIdx.x | y << 8 | z << 16 | wave << 24, its polls
+            unsigned v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipMemcpy(v, e->d_chain_err, sizeof(v), hipMemcpyDeviceToHost));
-            *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : n == "scalar_sweep_rescues" ? v[4] : v[2] / 100;
+            *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : n == "scalar_sweep_rescues" ? v[4] : n == "xchg_first_giveup_code" ? (v[5] & 0x7fffffffu)
+                   : n == "xchg_first_giveup_block" ? v[6] : n == "xchg_first_giveup_polls" ? v[7] : v[2] / 100;
         }
         else if (n == "resident_blocks") *value = e->resident_blocks;
         else if (n == "use_graph") *value = e->cfg.use_graph;
@@ -1652,6 +1673,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "fuse_layer") *value = fuse_layer(e) ? 1 : 0;
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
+        else if (n == "qkv_to_cache") *value = e->opt_qkv_to_cache;
         else if (n == "attn_impl") *value = e->opt_attn_impl;
         else if (n == "gemm_variant") *value = gemm_tile_variant();
         else if (n == "gemm256") *value = gemm256_enabled();

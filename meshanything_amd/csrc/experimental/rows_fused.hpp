@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void qkv_attn_rows_kernel(RowsFusedArgs A) {
             if (done[0] && done[1]) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, QA_ERR_GATHER);
+                if (lane == 0) xchg_raise(a.err, QA_ERR_GATHER, spins);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) if (!done[j]) { const int r = w + 4 * j; qg[r][lane] = 0.f; kvg[r][lane] = 0; kvg[r][64 + lane] = 0; }
                 break;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void qkv_attn_rows_kernel(RowsFusedArgs A) {
             if (!pend) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, RF_ERR_GATHER);
+                if (lane == 0) xchg_raise(a.err, RF_ERR_GATHER, spins);
                 for (int id = lane; id < NG; id += 64) pl[id / RF_PART][id % RF_PART] = id % RF_PART == 65 ? 1.f : 0.f;      // l = 1: no division by zero
                 break;
             }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_rows_kernel(RowsFusedArgs A) {
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
                     for (int r = 0; r < B; ++r)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) yraw[r * KC + w * 256 + k * 64 + lane] = 0.f;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_rows_kernel(RowsFusedArgs A) {
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
                     for (int r = 0; r < B; ++r)
 #pragma unroll
                         for (int k = 0; k < 8; ++k) reinterpret_cast<uint32_t*>(ffl + (size_t)r * KF)[w * 512 + k * 64 + lane] = 0u;

@@ -354,7 +354,9 @@ MA_NO_ASAN __device__ __forceinline__ void gt_glds4(const void* gsrc, unsigned l
                  : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
-template <typename HT, int ACT, int ABL = 0>
+// KV: the K / V column tiles of the prefill's q|k|v projection leave for the KV-cache planes (GemmTArgs::kv_*; a wave's 64 columns are one head, a
+// lane's 16-byte chunk of a row is one 16-byte chunk of a cache row: the same 16 stores, other addresses -- kv_fill2_kernel's pass over the tensor goes)
+template <typename HT, int ACT, int ABL = 0, bool KV = false>
 MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char g256_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
@@ -520,7 +522,19 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, i
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {
             const int r8 = lane >> 3, c = lane & 7;
-            bf16_t* dst = g.Cb + (size_t)(bm_e + wm * 128 + r8) * g.ldcb + (bn_e + wn * 64 + c * 8);
+            const int col0 = bn_e + wn * 64;
+            bf16_t* dst = g.Cb + (size_t)(bm_e + wm * 128 + r8) * g.ldcb + (col0 + c * 8);
+            const bool to_cache = KV && col0 >= g.kv_col0;           // (wave-uniform: a wave's 64 columns are one head of Q, K or V)
+            int kv_b = 0, kv_pos = 0;                                 // sample / position of this lane's row of the coming store
+            bf16_t* kv_plane = nullptr;
+            if constexpr (KV) {
+                if (to_cache) {
+                    const int m0 = bm_e + wm * 128 + r8;
+                    kv_b = m0 / g.kv_T; kv_pos = m0 - kv_b * g.kv_T;
+                    const int cc = col0 - g.kv_col0, isv = cc >= g.kv_col0 ? 1 : 0, head = (cc - isv * g.kv_col0) >> 6;
+                    kv_plane = (isv ? g.kv_v : g.kv_k) + (size_t)head * g.kv_max_seq * 64 + c * 8;
+                }
+            }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {                          // pass st: the wave's rows 32 st .. 32 st + 31
 #pragma unroll
@@ -540,7 +554,15 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, i
                 for (int it = 0; it < 4; ++it) { const int row = it * 8 + r8; q[it] = *reinterpret_cast<const u32x4*>(patch + row * 128 + ((c ^ (row & 7)) * 16)); }
                 if constexpr (!(ABL & 8)) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(dst + (size_t)(st * 32 + it * 8) * g.ldcb) = q[it];
+                for (int it = 0; it < 4; ++it) {
+                    bf16_t* p = dst + (size_t)(st * 32 + it * 8) * g.ldcb;
+                    if constexpr (KV) {
+                        if (to_cache) p = kv_plane + (size_t)kv_b * g.kv_row_stride + (size_t)kv_pos * 64;
+                        kv_pos += 8;                                  // the next store's row is 8 further (kv_T >= 8: at most one sample boundary)
+                        if (kv_pos >= g.kv_T) { kv_pos -= g.kv_T; ++kv_b; }
+                    }
+                    *reinterpret_cast<u32x4*>(p) = q[it];
+                }
                 } else { asm volatile("" :: "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3])); }
             }
         }
@@ -556,16 +578,16 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, i
 #undef G256_COMPUTE
 }
 
-template <typename HT, int ACT>
+template <typename HT, int ACT, bool KV = false>
 inline hipError_t g256p_launch(const GemmTArgs& g, int nty, int ntx, int n_cus, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<HT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS);
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<HT, ACT, 0, KV>), hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
     const int grid = nty * ntx <= n_cus ? nty * ntx : n_cus & ~7;      // (several rounds: a multiple of 8, so that a workgroup stays on its XCD's part of the tile list)
-    hipLaunchKernelGGL((gemm256p_kernel<HT, ACT>), dim3(grid), dim3(512), G256P_LDS, s, g, nty, ntx, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((gemm256p_kernel<HT, ACT, 0, KV>), dim3(grid), dim3(512), G256P_LDS, s, g, nty, ntx, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
@@ -594,8 +616,11 @@ inline int& gemm256_enabled() { static int v = 2; return v; }
 // gemm_tile.hpp entirely.  Outputs through a row map / a broadcast residual are not split (the encoder's, fp32 under enc_exact anyway).
 inline int g256_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
+// kv_rows (optional): with GemmTArgs::kv_k set, the number of leading rows whose K / V columns went to the cache planes (0: none -- the caller fills
+// the cache from the output tensor, as it does for the rows behind that count)
 template <typename HT>
-inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s) {
+inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s, int* kv_rows = nullptr) {
+    if (kv_rows) *kv_rows = 0;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
     // the 256-row tile's 16-bit-only epilogue (C == nullptr) carries no residual and stores 16 bytes to Cb: such calls take the 128-row tile
@@ -617,7 +642,13 @@ inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s
             // whole tiles with 16-bit output: the persistent form (next tile's operands requested before this tile's epilogue; its 4-KB-patch epilogue is
             // the faster one even where every workgroup has a single tile)
             const bool persist = gemm256_enabled() >= 2 && can_split && !g.C && g.Cb && !g.R && g.N % 256 == 0 && n_cus >= 8;
-            hipError_t r = persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
+            const bool kv = persist && kv_rows && g.kv_k && g.kv_v && g.act == ACT_NONE && g.kv_T >= 8 && g.kv_col0 % 64 == 0 && g.N == 3 * g.kv_col0;
+            if (kv) {
+                *kv_rows = nty * 256;
+                hipError_t r = g256p_launch<HT, ACT_NONE, true>(m, nty, ntx, n_cus, s);
+                if (r != hipSuccess) return r;
+            }
+            hipError_t r = kv ? hipSuccess : persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
                                                                                                                              : g256p_launch<HT, ACT_NONE>(m, nty, ntx, n_cus, s))
                                    : (g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s));
             const int rest = can_split ? g.M - nty * 256 : 0;

@@ -38,6 +38,10 @@ struct GemmTArgs {
     int r_mod;                      // > 0: residual row = m % r_mod (a per-sample table broadcast over the batch)
     RowMap cmap;                    // output row of logical row m
     int xcd_swizzle;                // 1: tiles handed out so that one XCD works on consecutive tiles (see the kernel)
+    // optional, honoured by the persistent 256 x 256 kernel only (gemm256.hpp; launch_gemm_dense reports how many rows it covered): the prefill's
+    // fused q|k|v projection writes its K and V columns -- [kv_col0, 2 kv_col0) and [2 kv_col0, 3 kv_col0), heads of 64 -- straight into the KV-cache
+    // planes instead of Cb: logical row m = sample m / kv_T, position m % kv_T -> plane[sample * kv_row_stride + (head * kv_max_seq + position) * 64 + d]
+    bf16_t* kv_k; bf16_t* kv_v; size_t kv_row_stride; int kv_max_seq, kv_T, kv_col0;
 };
 
 // MA_NO_ASAN: the LDS-DMA kernels stay uninstrumented in the sanitizer build (MA_DEBUG=asan): device ASan lowers a kernel's LDS to global

@@ -161,7 +161,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             if (!pend) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
+                if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
 #pragma unroll
                 for (int k = 0; k < NK; ++k) yr[k * 64 + lane] = 0.f;
                 break;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { fr[2 * (k * 64 + lane)] = 0.f; fr[2 * (k * 64 + lane) + 1] = 0.f; }
                     break;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                 if (!pend) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER);
+                    if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) yr[k * 64 + lane] = 0.f;
                     break;

@@ -169,7 +169,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
             }
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, QA_ERR_GATHER);
+                if (lane == 0) xchg_raise(a.err, QA_ERR_GATHER, spins);
                 qg[lane] = 0.f; kvg[lane] = 0; kvg[64 + lane] = 0;
                 break;
             }

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             if (__all((unsigned)(v1 >> 32) == epoch && (unsigned)(v2 >> 32) == epoch)) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, RA_ERR_QKV);
+                if (lane == 0) xchg_raise(a.err, RA_ERR_QKV, spins);
                 v1 = 0; v2 = 0;
                 break;
             }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
                 }
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, RA_ERR_QKV);
+                    if (lane == 0) xchg_raise(a.err, RA_ERR_QKV, spins);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) g[i] = u32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                     break;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
                 if (__all((unsigned)(vo >> 32) == epoch && (unsigned)(vm >> 32) == epoch)) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (xchg_expired(spins, t0, a.err)) {
-                    if (lane == 0) xchg_raise(a.err, ATTN_ERR_PAIR);
+                    if (lane == 0) xchg_raise(a.err, ATTN_ERR_PAIR, spins);
                     vo = 0; vm = 0;
                     break;
                 }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, RA_ERR_OUT);
+                if (lane == 0) xchg_raise(a.err, RA_ERR_OUT, spins);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = 0;
                 break;

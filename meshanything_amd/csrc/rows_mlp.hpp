@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, RM_ERR_FFN);
+                if (lane == 0) xchg_raise(a.err, RM_ERR_FFN, spins);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v[c] = 0;
                 break;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(1);
             if (xchg_expired(spins, t0, a.err)) {
-                if (lane == 0) xchg_raise(a.err, RM_ERR_FFN);
+                if (lane == 0) xchg_raise(a.err, RM_ERR_FFN, spins);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = 0;
                 break;

@@ -221,3 +221,24 @@ def mouse_variants(golden_dir, k):
         pc[:, 3:] /= np.linalg.norm(pc[:, 3:], axis=1, keepdims=True)
         out.append(normalize_pc(pc) if i else np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"])
     return torch.from_numpy(np.stack(out))
+
+import contextlib
+
+
+@contextlib.contextmanager
+def fused_path_must_hold(eng, what=""):
+    """Parity evidence must be evidence for the launches it names: a generation whose fused decode launches time out re-runs
+    on the five-launch chain and returns the same kind of answer, so a test that only looks at the answer can pass on the wrong kernels.  Wrapped
+    around every generation that is meant to exercise a fused launch: the engine's health counters -- generations that fell back, exchange sweeps
+    that gave up, scalar sweeps that a vector look had to finish -- must not move, and the fused launches must still be armed afterwards.  (The
+    fall-back itself has its own test, tests/test_gpu_fused_chain.py.)  Where the device cannot hold the fused grids (chain_resident == 0 from
+    the start) nothing is fused and nothing is checked."""
+    keys = ("chain_fallbacks", "xchg_timeouts", "scalar_sweep_rescues")
+    armed = eng.get_option("chain_resident") == 1
+    before = {k: eng.get_option(k) for k in keys}
+    yield
+    if armed:
+        after = {k: eng.get_option(k) for k in keys}
+        assert after == before and eng.get_option("chain_resident") == 1, (
+            f"{what}: the fused decode launches did not carry this generation (counters before {before}, after {after}, last exchange code "
+            f"{eng.get_option('xchg_last_code')}, chain_resident {eng.get_option('chain_resident')}): what was verified is the fall-back chain")

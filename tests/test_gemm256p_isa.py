@@ -28,7 +28,9 @@ def test_persistent_gemm_epilogue_issues_exactly_the_counted_operations():
     src = '#include "%s/gemm256.hpp"\nusing namespace ma;\n' % CSRC
     src += "void inst(GemmTArgs g) {\n" + "".join(
         "    hipLaunchKernelGGL((gemm256p_kernel<%s, %d, 0>), dim3(8), dim3(512), G256P_LDS, 0, g, 1, 1, (unsigned long long*)nullptr);\n" % (ht, act)
-        for ht in ("bf16_t", "f16_t") for act in (0, 1, 2)) + "}\n"
+        for ht in ("bf16_t", "f16_t") for act in (0, 1, 2)) + "".join(
+        "    hipLaunchKernelGGL((gemm256p_kernel<%s, 0, 0, true>), dim3(8), dim3(512), G256P_LDS, 0, g, 1, 1, (unsigned long long*)nullptr);\n" % ht
+        for ht in ("bf16_t", "f16_t")) + "}\n"
     with tempfile.TemporaryDirectory() as d:
         f = os.path.join(d, "inst.hip")
         with open(f, "w") as fh:
@@ -37,7 +39,7 @@ def test_persistent_gemm_epilogue_issues_exactly_the_counted_operations():
         subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-DNDEBUG", "-std=c++17", "-S", "--cuda-device-only", "-o", out, f], check=True, capture_output=True)
         text = open(out).read()
     kernels = re.findall(r"^(_ZN2ma15gemm256p_kernel\w+):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M)
-    assert len(kernels) == 6, [k for k, _ in kernels]
+    assert len(kernels) == 8        # 2 formats x {3 activations, the K / V -> cache form}, [k for k, _ in kernels]
     for name, body in kernels:
         assert "scratch_" not in body, name + ": spills"
         ops = [ln.split()[0] for ln in body.splitlines() if VMEM.match(ln)]

@@ -8,7 +8,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
-from conftest import mouse_variants, cached_state_dict, load_weights_cached, oracle_device
+from conftest import mouse_variants, cached_state_dict, fused_path_must_hold, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 
@@ -489,7 +489,8 @@ def test_full_generate_matches_oracle(full, golden_dir):
     x = torch.from_numpy(d["mouse_norm"])[None]
     prefix = full.oracle.process_point_feature(full.oracle.encode_latents(x))
     n = int(os.environ.get("MA_TEST_GEN_TOKENS", "400"))
-    toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+    with fused_path_must_hold(full.engine, f"{full.policy} batch 1"):
+        toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
     v = _check_greedy(full, prefix, toks, lengths, suppress_eos=True)
     nd = assert_diverse(toks, 48, "350M greedy decode")
     print(f"[{full.policy}] {n}-token greedy decode ({nd} distinct ids) vs oracle: {v}")
@@ -504,7 +505,8 @@ def test_full_batched_generate_matches_oracle(full, golden_dir):
     x = mouse_variants(golden_dir, 6)                   # row 0 = mouse.npy itself
     prefix = full.oracle.process_point_feature(full.oracle.encode_latents(x))
     n = 160
-    toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+    with fused_path_must_hold(full.engine, f"{full.policy} batch 6"):
+        toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
     assert toks.shape == (6, n)
     v = _check_greedy(full, prefix, toks, lengths, suppress_eos=True)
     nd = [assert_diverse(toks[b], 24, f"batch row {b}") for b in range(6)]
@@ -581,7 +583,8 @@ def test_v2_scale_1600_faces(golden_dir):
     load_weights_cached(env.engine, cfg, init=FULL_INIT)
     x = mouse_variants(golden_dir, 8)
     prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
-    toks, lengths = env.engine.generate(prefix.cuda(), max_new_tokens=96, suppress_eos=True)
+    with fused_path_must_hold(env.engine, "1600 faces, batch 8"):
+        toks, lengths = env.engine.generate(prefix.cuda(), max_new_tokens=96, suppress_eos=True)
     assert toks.shape == (8, 96)
     v = _check_greedy(env, prefix, toks, lengths, suppress_eos=True)
     assert all(r["ambiguous"] <= 8 for r in v), [r["ambiguous"] for r in v]
@@ -631,4 +634,34 @@ def test_v2_scale_config3_batch64_sampling(golden_dir):
     assert q[2] <= 0.07 and float(d.max()) <= 0.16, (q, float(d.max()))
     # rows are distinct shapes: their streams differ
     assert len({tuple(r.tolist()) for r in toks.cpu()}) > B // 2
+    eng.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp16"])
+def test_prefill_kv_written_by_the_qkv_gemm_equals_the_copy(golden_dir, policy):
+    """Round 6: at 64 samples the prefill's q|k|v projection runs on the persistent 256 x 256 tiles, whose epilogue writes the K / V columns straight
+    into the KV-cache planes (csrc/gemm256.hpp, KV form); the 64-row tail of M = 64 x 257 is copied from the tensor, and attention reads K / V from
+    the planes.  Option qkv_to_cache = 0 copies every row instead (kv_fill_rows_kernel), gemm256 = 1 takes the one-tile kernel (no KV form): the three
+    must give the same cache, i.e. the same logits bit for bit over the prefill's token and 24 decode steps that read every cached position."""
+    from meshanything_amd.engine import Engine
+    B, n = 64, 24
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=B)
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=FULL_INIT)
+    g = torch.Generator().manual_seed(11)
+    prefix = (torch.randn(B, cfg.num_latents + 1, cfg.hidden, generator=g) * 0.5).cuda()
+    assert eng.get_option("qkv_to_cache") == 1 and eng.get_option("gemm256") == 2
+    ref = None
+    try:
+        for (to_cache, g256) in ((1, 2), (0, 2), (1, 1), (1, 2)):
+            eng.set_option("qkv_to_cache", to_cache); eng.set_option("gemm256", g256)
+            t, _, lg = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, return_logits=True)
+            if ref is None:
+                ref = (t.clone(), lg.clone())
+                assert_diverse(t, 24, "kv-to-cache reference stream")
+                continue
+            assert torch.equal(ref[0], t), f"tokens differ with qkv_to_cache={to_cache} gemm256={g256}"
+            assert torch.equal(ref[1].view(torch.int32), lg.view(torch.int32)), f"logits differ with qkv_to_cache={to_cache} gemm256={g256}"
+    finally:
+        eng.set_option("qkv_to_cache", 1); eng.set_option("gemm256", 2)
     eng.close()
