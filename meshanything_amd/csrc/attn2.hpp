@@ -17,8 +17,11 @@
 //     the q/k/v GEMM; the transposition costs one pass over 2-byte data instead of 16 two-byte LDS stores per thread and tile).
 //     A = the V^T tile (d x keys) from LDS, again one ds_read_b128 per MFMA.
 //   * one block = NW waves x 32 query rows (NW = 3 for the 257-row sequences: 96-row blocks waste 11 %, 128-row blocks a third of their
-//     staging), K / V^T tiles of 64 keys in a double-buffered LDS ring filled through registers: the global loads of tile t + 1 are
-//     issued before the 16 MFMAs of tile t and written to the other buffer after them -- ONE barrier per tile;
+//     staging), K / V^T tiles of 64 keys in a THREE-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, the
+//     bank swizzle on the SOURCE address: the DMA writes lane-linear): the pieces of tile t + 2 are requested before the 16 MFMAs of tile t, a
+//     counted vmcnt leaves them in flight across the tile's ONE barrier.  (Round 5's form staged tile t + 1 through registers -- requested before
+//     the MFMAs, written to LDS after them -- so every tile ended on the full latency of its successor's loads: a block was a chain of round
+//     trips, 9 % matrix-core busy on the 257-row sequences.)
 //   * both tiles are [64 rows][128 bytes] with the 16-byte chunk index XOR (row >> 1) & 7: conflict-free for the hardware's 16-lane
 //     ds_read_b128 groups when the 32 lanes of a half-wave read 32 different rows (checked by enumeration);
 //   * the output leaves through a per-wave LDS patch so that a row is stored as whole 128-byte lines.
@@ -29,6 +32,7 @@
 #include "attn.hpp"
 #include "common.hpp"
 #include "gemm.hpp"
+#include "gemm_tile.hpp"
 
 namespace ma {
 
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
 template <int NW, typename HT = bf16_t>
 __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a) {
     constexpr int NT = NW * 64, RB = NW * 32, TILE = 64 * 128;         // threads, query rows per block, bytes of one K or V^T tile
-    constexpr int NCH = (512 + NT - 1) / NT;                            // 16-byte chunks per thread, tile and operand
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];   // ring of two stages x {K, V^T}; reused for the output patches
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, hi = lane >> 5;
+    constexpr int NST = 3;                                              // ring stages
+    __shared__ __attribute__((aligned(16))) char smem[NST * 2 * TILE]; // ring of three stages x {K, V^T}; reused for the output patches
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * RB;
     const bf16_t* Qp = a.Q + (size_t)b * a.q_bs + (size_t)h * a.q_hs;
     const bf16_t* Kp = a.K + (size_t)b * a.k_bs + (size_t)h * a.k_hs;
@@ -116,31 +120,27 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a
     if (a.causal_offset >= 0) kv_end = min(a.Sk, a.causal_offset + min(q0 + RB - 1, a.Sq - 1) + 1);
     const int nt = (kv_end + 63) >> 6;
 
-    u32x4 kreg[NCH], vreg[NCH];
-    auto gload = [&](int t) {
+    // LDS-DMA of tile t into ring stage t % 3: 16 pieces of 1 KiB (8 K pieces = 8 key rows each, 8 V^T pieces = 8 d rows each), piece p by wave p % NW.
+    // Lane l of a piece lands at byte 16 l = row l >> 3, slot l & 7 of the piece: it fetches the chunk whose swizzled slot that is (a2_slot is an
+    // XOR: its own inverse).  Key rows past Sk repeat the last row: their scores are masked below (key <= klimit); V^T is zero-padded by
+    // vt_pack_kernel.  No lane-dependent branch around a request.
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int drow = lane >> 3, dslot = lane & 7;
+    auto stage = [&](int t) {
         const int kv0 = t << 6;
-        // Requests with clamped indices, no branch around them: the guarded form (`if (row < Sk) k = load`) made hipcc wait for tile t + 1
-        // right here, in front of tile t's MFMAs -- the prefetch was not one (ISA: s_waitcnt vmcnt(0) before the first MFMA of every tile;
-        // matrix cores busy 0.20 / 0.09 in the 128- / 96-row kernels).  Key rows past Sk repeat the last row: their scores are masked
-        // below (key <= klimit); V^T is zero-padded by vt_pack_kernel.  Chunks past 512 (NW = 3) repeat chunk 511 and are not stored.
+        const unsigned base = lds0 + (unsigned)(t % NST) * (2u * TILE);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int id = min(tid + NT * i, 511), r = id >> 3, c = id & 7;
-            kreg[i] = *reinterpret_cast<const u32x4*>(Kp + (size_t)min(kv0 + r, a.Sk - 1) * a.k_rs + c * 8);
-            vreg[i] = *reinterpret_cast<const u32x4*>(Vp + (size_t)r * a.skp + kv0 + c * 8);
+        for (int i = 0; i < (16 + NW - 1) / NW; ++i) {
+            const int p = w + NW * i;                                    // (wave-uniform)
+            if (NW * i + NW > 16 && p >= 16) continue;
+            const int r = (p & 7) * 8 + drow, c = dslot ^ ((r >> 1) & 7);
+            const bf16_t* ks = Kp + (size_t)min(kv0 + r, a.Sk - 1) * a.k_rs + c * 8;
+            const bf16_t* vs = Vp + (size_t)r * a.skp + kv0 + c * 8;
+            gt_glds16(p < 8 ? ks : vs, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
         }
     };
-    auto lstore = [&](int stage) {
-        char* kb = smem + stage * 2 * TILE;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = id & 7;
-            if (NT * NCH == 512 || id < 512) {
-                *reinterpret_cast<u32x4*>(kb + r * 128 + a2_slot(r, c) * 16) = kreg[i];
-                *reinterpret_cast<u32x4*>(kb + TILE + r * 128 + a2_slot(r, c) * 16) = vreg[i];
-            }
-        }
-    };
+    // pieces this wave requests per tile: the counted wait at a tile's end leaves exactly one tile's worth in flight
+    const int my_pieces = (16 - w + NW - 1) / NW;
 
     f32x16 oacc[2];
 #pragma unroll
@@ -148,15 +148,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a
     float mrun = -1e30f, lsum = 0.f;
     const float sc2 = a.scale * 1.44269504088896340736f;               // scores in the log2 domain: exp(x) = exp2(x log2 e)
 
-    if (nt > 0) { gload(0); lstore(0); }
-    // every request made so far (the Q fragments above all) is retired HERE, on every path: otherwise hipcc's wait-count pass carries "Q may
-    // still be in flight" into the loop (the nt == 0 path skips the waits of lstore) and guards the first MFMAs of EVERY tile with vmcnt(3..0)
-    // -- i.e. waits for the tile t + 1 prefetch it has just issued
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0)
+    if (nt > 0) stage(0);
+    // every request made so far (the Q fragments, tile 0) is retired HERE, on every path: hipcc's wait-count pass must not carry "Q may still be in
+    // flight" into the loop (it would guard the first MFMAs of every tile with vmcnt(3..0)); the DMA requests are invisible to it and counted by hand
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0) -- the BUILTIN: the wait-count pass must see it
+    if (nt > 1) stage(1);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gload(t + 1);                                   // flies under this tile's MFMAs
-        const char* kb = smem + (t & 1) * 2 * TILE;
+        if (t + 2 < nt) stage(t + 2);                                   // ring stage (t + 2) % 3 = (t - 1) % 3: last read during tile t - 1, before the previous barrier
+        const char* kb = smem + (t % NST) * 2 * TILE;
         const char* vb = kb + TILE;
         // ---- S^T = K Q^T: two 32-key blocks x four 16-deep steps ---------------------------------------------------------------------
         f32x16 sacc[2];
@@ -215,7 +215,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a
                 oacc[db] = H16<HT>::mfma32(vf, pf[s], oacc[db]);
             }
         }
-        if (t + 1 < nt) lstore((t + 1) & 1);                            // the other stage: last read during tile t - 1, before the previous barrier
+        // tile t + 1 has landed (this wave's pieces: requested one tile ago; tile t + 2's stay in flight), then everyone's: ONE barrier per tile.
+        // (the barrier is a bare s_barrier behind lgkmcnt(0): hipcc does not know of the DMA requests, so __syncthreads() carries no vmcnt(0))
+        if (t + 2 < nt) {
+            if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     // ---- epilogue: normalise, round, and store whole rows through this wave's LDS patch (32 rows x 128 bytes) ----------------------------

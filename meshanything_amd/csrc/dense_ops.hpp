@@ -38,10 +38,12 @@ __global__ void fourier2_kernel(const PT* __restrict__ pc, int n_rows, int F, AT
 // NVT > 0: D == 256 NVT exactly -- every lane owns NVT chunks, no lane-dependent guard: the row's NVT requests and the 2 NVT parameter
 // requests all go out before the first use (hipcc waits for a request made inside a lane-dependent branch where the branch ends: the
 // guarded form, NVT == 0, is one round trip per chunk and streamed 1.8 TB/s; profiles/r04_dense_b64_kernel_stats.csv).
-template <typename AT, int NVT>
+// KS > 1 (NVT > 0 only): the input of rows < split_rows is the sum of KS partial buffers x + p * part_stride (a GEMM split along K, gemm256.hpp
+// GemmSplitK), added up in ascending p; rows behind split_rows are complete in part 0.  All KS x NVT requests of a row go out first.
+template <typename AT, int NVT, int KS = 1>
 __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__ x, int ldx, RowMap xin, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, float* y32, int ld32, AT* __restrict__ ya,
-                                                       int lda, RowMap yout, int rows, int D) {
+                                                       int lda, RowMap yout, int rows, int D, long part_stride = 0, int split_rows = 0) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + xin(row) * ldx;
@@ -53,6 +55,19 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
     if constexpr (NVT > 0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + 4 * (lane + 64 * j));
+        if constexpr (KS > 1) {
+            if (row < split_rows) {                               // (one row per wave: a wave-uniform branch)
+                f32x4 pv[KS - 1][NV];
+#pragma unroll
+                for (int p = 1; p < KS; ++p)
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) pv[p - 1][j] = *reinterpret_cast<const f32x4*>(xr + (size_t)p * part_stride + 4 * (lane + 64 * j));
+#pragma unroll
+                for (int p = 1; p < KS; ++p)
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) { v[j].x += pv[p - 1][j].x; v[j].y += pv[p - 1][j].y; v[j].z += pv[p - 1][j].z; v[j].w += pv[p - 1][j].w; }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) { g4[j] = *reinterpret_cast<const f32x4*>(g + 4 * (lane + 64 * j)); b4[j] = *reinterpret_cast<const f32x4*>(b + 4 * (lane + 64 * j)); }
         asm volatile("" ::: "memory");
@@ -96,8 +111,10 @@ __global__ __launch_bounds__(256) void ln_rows2_kernel(const float* __restrict__
 }
 template <typename AT>
 inline void launch_ln_rows2(const float* x, int ldx, RowMap xin, const float* g, const float* b, float eps, float* y32, int ld32, AT* ya, int lda,
-                            RowMap yout, int rows, int D, hipStream_t s) {
+                            RowMap yout, int rows, int D, hipStream_t s, int parts = 1, long part_stride = 0, int split_rows = 0) {
     const dim3 grid((rows + 3) / 4), block(256);
+    if (parts == 4 && D == 1024) { hipLaunchKernelGGL((ln_rows2_kernel<AT, 4, 4>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D, part_stride, split_rows); return; }
+    if (parts == 2 && D == 1024) { hipLaunchKernelGGL((ln_rows2_kernel<AT, 4, 2>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D, part_stride, split_rows); return; }
     if (D == 1024) hipLaunchKernelGGL((ln_rows2_kernel<AT, 4>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
     else if (D == 768) hipLaunchKernelGGL((ln_rows2_kernel<AT, 3>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);
     else if (D == 512) hipLaunchKernelGGL((ln_rows2_kernel<AT, 2>), grid, block, 0, s, x, ldx, xin, g, b, eps, y32, ld32, ya, lda, yout, rows, D);

@@ -157,6 +157,10 @@ struct ma_engine {
     int dense_rows = 1, prefill_rows = 1;
     float *w_data = nullptr, *w_lat = nullptr, *w_lat2 = nullptr, *w_pf = nullptr, *w_x = nullptr, *w_y = nullptr, *w_fe = nullptr, *w_logit = nullptr;
     float *p_h = nullptr, *p_y = nullptr;
+    long p_y_part_stride = 0;        // p_y holds up to 4 partial sums of a GEMM split along K (gemm256.hpp GemmSplitK), this many floats apart, for the small prefills that use it
+    int opt_fuse_ln = 0;             // (MA_EXPERIMENTAL builds; measured, not kept) prefill: the two LayerNorms of a layer finished inside the out_proj / fc2 GEMMs where those run on whole 256 x 256 tiles (gemm256.hpp LNF form; needs the grid resident like every in-launch exchange: chain_resident)
+    u64* d_ln_gran = nullptr; size_t ln_gran_tiles = 0; unsigned ln_epoch = 0;
+    int opt_gemm_splitk = 1;         // prefill fc2 of small batches as 4 partial sums along K, added up by the LayerNorm that follows (0: never; A/B)
     void *a_feat = nullptr, *a_dataln = nullptr, *a_kv = nullptr, *a_q = nullptr, *a_ln = nullptr, *a_qkv = nullptr, *a_att = nullptr, *a_mlp = nullptr,
          *a_cat = nullptr, *a_mean = nullptr, *a_fein = nullptr, *a_x = nullptr, *a_ph = nullptr, *a_pqkv = nullptr, *a_patt = nullptr, *a_pffn = nullptr;
     unsigned char* w_mask = nullptr;
@@ -266,7 +270,7 @@ struct GemmOut {                       // exactly one of: fp32 stream output | a
 // kv->rows_done = the leading rows for which they did
 struct KvDst { void* k = nullptr; void* v = nullptr; size_t row_stride = 0; int max_seq = 0, T = 0, col0 = 0; int rows_done = 0; };
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr, GemmOut out,
-          int M, int act, int r_mod = 0, KvDst* kv = nullptr) {
+          int M, int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr) {
     const Entry& en = e->L.get(w);
     const float* bias = bias_name ? e->PF(bias_name) : nullptr;
     hipError_t r;
@@ -277,7 +281,7 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
         t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
         if (kv) { t.kv_k = reinterpret_cast<bf16_t*>(kv->k); t.kv_v = reinterpret_cast<bf16_t*>(kv->v); t.kv_row_stride = kv->row_stride; t.kv_max_seq = kv->max_seq; t.kv_T = kv->T; t.kv_col0 = kv->col0; }
-        r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s, kv ? &kv->rows_done : nullptr));
+        r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s, kv ? &kv->rows_done : nullptr, sk, lnf));
     } else {
         GemmArgs g{};
         g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
@@ -288,19 +292,50 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, "gemm launch failed for " + w + ": " + hipGetErrorString(r));
 }
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr, GemmOut out, int M,
-          int act, int r_mod = 0, KvDst* kv = nullptr) {
-    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod, kv);
+          int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr) {
+    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod, kv, sk, lnf);
 }
+
 GemmOut to32(float* c, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.c32 = c; o.ld = ld; o.map = m; return o; }
 GemmOut toact(void* a, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.act = a; o.ld = ld; o.map = m; return o; }
 
 // LayerNorm rows: x fp32 (row map xin) -> y32 (fp32, optional) and ya (activation, optional), both at row map yout
+// (parts > 1: the input of the first split_rows rows is the sum of `parts` buffers part_stride floats apart -- a GEMM split along K)
 void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::string& prefix, float eps, float* y32, int ld32, void* ya, int lda, int rows,
-            int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}) {
+            int D, RowMap xin = RowMap{0, 0, 0}, RowMap yout = RowMap{0, 0, 0}, int parts = 1, long part_stride = 0, int split_rows = 0) {
     const float* g = e->PF(prefix + "weight"); const float* b = e->PF(prefix + "bias");
-    if (e->dense16) H16_DO(e->hdt, HT, launch_ln_rows2<HT>(x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<HT*>(ya), lda, yout, rows, D, s));
+    if (parts > 1 && !(e->dense16 && D == 1024 && (parts == 2 || parts == 4))) throw MaError(MA_ERR_INVALID, "internal: LayerNorm over a split input needs a 16-bit phase and 1024 columns");
+    if (e->dense16) H16_DO(e->hdt, HT, launch_ln_rows2<HT>(x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<HT*>(ya), lda, yout, rows, D, s, parts, part_stride, split_rows));
     else launch_ln_rows2<float>(x, ldx, xin, g, b, eps, y32, ld32, reinterpret_cast<float*>(ya), lda, yout, rows, D, s);
     HIP_CHECK(hipGetLastError());
+}
+// h = LN(h + A W^T + b) for M stacked rows, fp32 in place + 16-bit copy hb (the two post-LN sub-layers of an OPT layer, [3p] OPTDecoderLayer): the GEMM
+// finishes the LayerNorm itself where it can (gemm256.hpp LNF form: whole 256-row tiles of a launch that fills the chip); the row kernel does the rest from
+// the plain sums in `y`.  split: fc2 of small batches may come as partial sums along K instead (GemmSplitK), which the row kernel adds up.
+void gemm_res_ln(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const std::string& ln_prefix, float eps, float* h, void* hb,
+                 float* y, int M, int H, bool allow_split) {
+    const bool fuse = e->opt_fuse_ln && e->dense16 && e->chain_resident && e->d_ln_gran && (size_t)(M / 256) * (size_t)(H / 256) <= e->ln_gran_tiles;
+    GemmSplitK sk;
+    sk.max_parts = (allow_split && e->opt_gemm_splitk && e->dense16 && H == 1024 && (long)M * H <= e->p_y_part_stride) ? 4 : 1;
+    sk.part_stride = e->p_y_part_stride;
+    if (fuse) {
+        GemmLnFuse lf;
+        lf.ln.gamma = e->PF(ln_prefix + "weight"); lf.ln.beta = e->PF(ln_prefix + "bias"); lf.ln.eps = eps; lf.ln.gran = e->d_ln_gran; lf.ln.err = e->d_chain_err;
+        if (++e->ln_epoch == 0) e->ln_epoch = 1;
+        lf.ln.epoch = e->ln_epoch;
+        lf.tail_c = y;
+        GemmOut o; o.c32 = h; o.act = hb; o.ld = H;
+        gemm(e, s, A, lda, w, b, h, H, o, M, ACT_NONE, 0, nullptr, &sk, &lf);
+        if (lf.rows < M) {
+            const size_t r0 = (size_t)lf.rows;
+            // (a split GEMM never takes the LNF form: then lf.rows == 0 and the parts cover sk.rows rows from row 0)
+            lnrows(e, s, y + r0 * H, H, ln_prefix, eps, h + r0 * H, H, reinterpret_cast<char*>(hb) + r0 * H * e->act_elem, H, M - lf.rows, H, RowMap{0, 0, 0}, RowMap{0, 0, 0},
+                   sk.parts, sk.part_stride, sk.rows);
+        }
+        return;
+    }
+    gemm(e, s, A, lda, w, b, h, H, to32(y, H), M, ACT_NONE, 0, nullptr, &sk);
+    lnrows(e, s, y, H, ln_prefix, eps, h, H, hb, H, M, H, RowMap{0, 0, 0}, RowMap{0, 0, 0}, sk.parts, sk.part_stride, sk.rows);
 }
 // attention over activation tensors; strides in elements; batch = samples (grid.z)
 void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, const void* K, int k_rs, int k_hs, const void* Vp, int v_rs, int v_hs, void* O,
@@ -1093,11 +1128,11 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
             attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
                       (size_t)T * 3 * H, (size_t)T * H);
         }
-        gemm(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", h, H, to32(y, H), M, ACT_NONE);
-        lnrows(e, s, y, H, p + "self_attn_layer_norm.", 1e-5f, h, H, hb, H, M, H);
+        gemm_res_ln(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, false);
         gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU);
-        gemm(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", h, H, to32(y, H), M, ACT_NONE);
-        lnrows(e, s, y, H, p + "final_layer_norm.", 1e-5f, h, H, hb, H, M, H);
+        // small batches: fc2's 256 x 256 tiles (N = hidden: four per tile row) fill a fraction of the chip while each runs 64 K-tiles -- split along K
+        // into partial sums that the LayerNorm adds up (gemm256.hpp GemmSplitK; 16 samples: 64 tiles x 4 parts = one round of 16 K-tiles)
+        gemm_res_ln(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", p + "final_layer_norm.", 1e-5f, h, hb, y, M, H, true);
     }
     // only the last prefix row of every sample feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
     enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, T * H, nullptr, nullptr, none, Rows{row0, B});
@@ -1189,6 +1224,7 @@ int generate_batch_once(ma_engine* e, hipStream_t s, const float* prefix, int B,
         finished = true;
         for (int b = 0; b < B; ++b) finished = finished && e->h_state[b].finished != 0;
     }
+    if (produced == 1 && impl == 0) check_chain_error(e, s);            // (no decode step ran: the prefill's own in-launch exchange -- gemm256.hpp LNF form -- is checked here)
     HIP_CHECK(hipMemcpyAsync(e->h_tokens, e->w_tokens, (size_t)total * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     int nmax = 0;
@@ -1436,7 +1472,12 @@ void build_engine(ma_engine* e) {
     e->a_x = amalloc(R * S * Wt);
     {
         const size_t PR = R * T;
-        e->p_h = e->dmalloc<float>(PR * H); e->p_y = e->dmalloc<float>(PR * H);
+        const size_t PS = std::min<size_t>(PR, 10240);           // (a split GEMM has fewer than 0.6 x CUs tiles of 256 x 256: at most ~40 tile rows)
+        e->p_y_part_stride = (long)(PS * H);
+        e->p_h = e->dmalloc<float>(PR * H); e->p_y = e->dmalloc<float>(std::max(PR, 4 * PS) * H);
+        e->ln_gran_tiles = (PR / 256 + 1) * (size_t)((H + 255) / 256);
+        e->d_ln_gran = e->dmalloc<u64>(2 * e->ln_gran_tiles * 256);
+        HIP_CHECK(hipMemset(e->d_ln_gran, 0, 2 * e->ln_gran_tiles * 256 * sizeof(u64)));
         e->a_ph = amalloc(PR * H); e->a_pqkv = amalloc(PR * 3 * H); e->a_patt = amalloc(PR * H); e->a_pffn = amalloc(PR * c.ffn);
     }
     const size_t B = c.max_batch;
@@ -1582,6 +1623,13 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "qkv_to_cache") e->opt_qkv_to_cache = value ? 1 : 0;
+        else if (n == "gemm_splitk") e->opt_gemm_splitk = value ? 1 : 0;
+        else if (n == "fuse_ln") {
+#ifndef MA_EXPERIMENTAL
+            if (value) throw MaError(MA_ERR_STATE, "fuse_ln needs a library built with MA_EXPERIMENTAL=1 (LayerNorm inside the GEMM epilogue: measured, not kept)");
+#endif
+            e->opt_fuse_ln = value ? 1 : 0;
+        }
         else if (n == "gemm256") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "gemm256: 0 (128-row tiles), 1 (one tile per workgroup) or 2 (1 + the persistent form)"); gemm256_enabled() = (int)value; }
         else if (n == "attn_impl") { if (value != 1 && value != 2) throw MaError(MA_ERR_INVALID, "attn_impl: 1 (attn.hpp) or 2 (attn2.hpp)"); e->opt_attn_impl = (int)value; }
         else if (n == "gemm_variant") {
@@ -1674,6 +1722,8 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "attn_final_waves") *value = e->opt_attn_final_waves;
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "qkv_to_cache") *value = e->opt_qkv_to_cache;
+        else if (n == "gemm_splitk") *value = e->opt_gemm_splitk;
+        else if (n == "fuse_ln") *value = e->opt_fuse_ln && e->chain_resident;      // (effective)
         else if (n == "attn_impl") *value = e->opt_attn_impl;
         else if (n == "gemm_variant") *value = gemm_tile_variant();
         else if (n == "gemm256") *value = gemm256_enabled();

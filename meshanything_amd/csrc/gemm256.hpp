@@ -49,16 +49,42 @@ template <int N> __device__ __forceinline__ void g256_wait_vm() { asm volatile("
 // EV (scripts/ubench_gemm256_epi.hip only; G256_EV in the library): epilogue form bits -- 2 the straight-line form of whole tiles (all LDS reads /
 // residual loads of a pass issued first, then the stores); (bit 1, the hardware 16-bit conversion, became common.hpp's f2bf / pack2)
 constexpr int G256_EV = 2;
-template <typename HT, int ACT, int ABL = 0, int EV = G256_EV>
-MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr) {
+// LNF: the LayerNorm that follows an N = hidden GEMM (post-LN layers: h = LN(h + W a + b), [3p] OPTDecoderLayer; shape_opt.py:403-410) finished INSIDE the
+// GEMM's epilogue instead of by a row kernel that re-reads the sum (ln_rows2_kernel: 168 MB per call at 64 samples, 30 us of a 600-us layer, twice per
+// layer).  A row spans the ntx = N / 256 tiles of its tile row, i.e. ntx workgroups: they exchange per-row moments through 8-byte {epoch, value} granules
+// (common.hpp ps_publish; MI355X guide, Guideline 16 R2) in two rounds -- row sums -> mean, then sums of squared deviations -> variance: the exact
+// two-pass form of ln_rows2_kernel -- and each normalises its own 256 columns: outputs h (fp32, in place over the residual it read) and its 16-bit copy.
+// Order of every sum is fixed (4 columns of a lane, the DPP tree over 16 lanes, the four waves of a tile, the tiles in ascending order), so all tiles
+// of a row compute the same mean / rstd bit for bit and the result does not depend on timing.  The workgroups of a tile row are consecutive in the
+// tile list; a sweep is bounded like every in-launch exchange of this engine (20 ms, then the error word: the generation is re-run without the fused
+// forms, engine.hip generate_batch).  Whole tiles only, K not split.
+struct G256Ln {
+    const float* gamma; const float* beta; float eps;
+    u64* gran;                     // [2][nty * ntx][256]: row sums | sums of squared deviations, one granule per (tile, row)
+    unsigned* err;                 // the engine's error words (common.hpp xchg_raise)
+    unsigned epoch;                // unique per launch, never 0 (the buffer starts zeroed)
+};
+constexpr unsigned G256_ERR_LN = 2048;
+constexpr int G256_LN_LDS = 8192;  // LDS behind the operand buffers: [4 waves][256] partial sums, [256] mean, [256] rstd
+template <typename HT, int ACT, int ABL = 0, int EV = G256_EV, bool LNF = false>
+MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, int nty, int ntx, unsigned long long* trace = nullptr, int ks = 1, long part_stride = 0, G256Ln ln = G256Ln{}) {
     extern __shared__ __attribute__((aligned(16))) char g256_smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 2, wn = w & 3;
     // XCD-aware hand-out: workgroups go to the XCDs round-robin; XCD i works on the i-th eighth of this launch's tile range
-    int t = blockIdx.x;
+    // ks > 1 (fp32 output only): split along K -- the grid is ks x the tile list, launch part `split` accumulates k in [split K / ks, (split + 1) K / ks)
+    // into the fp32 buffer g.C + split * part_stride (bias and residual go into part 0; the consumer -- ln_rows2_kernel -- adds the parts up).  For
+    // the N = hidden GEMMs of small batches, whose 256 x 256 tiles fill a fraction of the chip (fc2 at 16 samples: 64 tiles x 64 K-tiles)
+    int t = blockIdx.x, split = 0;
+    const int tiles = gridDim.x / ks;
+    if (ks > 1) { split = t / tiles; t -= split * tiles; }
     {
-        const int tiles = gridDim.x, xcd = t & 7, i = t >> 3, lo = tiles >> 3, rem = tiles & 7;
+        const int xcd = t & 7, i = t >> 3, lo = tiles >> 3, rem = tiles & 7;
         t = xcd * lo + min(xcd, rem) + i;
     }
+    const int kbeg = split * (g.K / ks);
+    const float* const biasp = split == 0 ? g.bias : nullptr;
+    const float* const Rp = split == 0 ? g.R : nullptr;
+    float* const Cp = g.C ? g.C + (size_t)split * part_stride : nullptr;
     int tile_y, tile_x;
     {
         const int fullp = ntx >> 2, tailw = ntx & 3, cut = fullp * 4 * nty;
@@ -67,7 +93,7 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
     }
     const int bm = tile_y * 256, bn = tile_x * 256;
     const unsigned lds0 = (unsigned)(size_t)g256_smem;
-    const int nk = g.K >> 6;
+    const int nk = (g.K / ks) >> 6;
 
     // ---- LDS-DMA: instruction p (0 .. 15) of a piece covers piece rows 8 p .. 8 p + 7; this wave issues p = w and w + 8 ---------------------
     const int drow = lane >> 3, dslot = lane & 7;
@@ -80,8 +106,8 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
             const int sw = (dslot ^ (pr & 7)) * 8;                   // swizzled 16-byte chunk of the source row
             const int m = min(bm + (pr >> 6) * 128 + s * 64 + (pr & 63), g.M - 1);
             const int n = min(bn + (pr >> 5) * 64 + s * 32 + (pr & 31), g.N - 1);
-            xsrc[s][i] = g.A + (size_t)m * g.lda + sw;
-            wsrc[s][i] = g.W + (size_t)n * g.K + sw;
+            xsrc[s][i] = g.A + (size_t)m * g.lda + sw + kbeg;
+            wsrc[s][i] = g.W + (size_t)n * g.K + sw + kbeg;
         }
     auto stage_x = [&](int s, int kt) {
         if constexpr (ABL & 1) { if (kt > 0) return; }
@@ -197,9 +223,9 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
         for (int i = 0; i < 2; ++i) {
             const int n0 = bn + wn * 64 + b * 32 + i * 16 + kg * 4;
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (g.bias) {
-                if (n0 + 3 < g.N) b4 = *reinterpret_cast<const f32x4*>(g.bias + n0);
-                else { if (n0 < g.N) b4.x = g.bias[n0]; if (n0 + 1 < g.N) b4.y = g.bias[n0 + 1]; if (n0 + 2 < g.N) b4.z = g.bias[n0 + 2]; }
+            if (biasp) {
+                if (n0 + 3 < g.N) b4 = *reinterpret_cast<const f32x4*>(biasp + n0);
+                else { if (n0 < g.N) b4.x = biasp[n0]; if (n0 + 1 < g.N) b4.y = biasp[n0 + 1]; if (n0 + 2 < g.N) b4.z = biasp[n0 + 2]; }
             }
             bias4[b][i] = b4;
         }
@@ -207,7 +233,7 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
     // whole tiles with plain row addressing take the straight-line form: every LDS read (and residual load) of a pass is issued before the first
     // store, so a pass costs one LDS / memory round trip instead of one per store (the guarded loop below waits for each chunk in turn)
     const bool whole = (EV & 2) && bm + 256 <= g.M && bn + 256 <= g.N && g.cmap.grp == 0 && g.r_mod == 0;
-    if (g.C == nullptr) {
+    if (Cp == nullptr) {
         // 16-bit output only: patch rows of 128 B (64 elements), chunk = 8 elements
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -255,11 +281,12 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
         // whole tiles: four passes of 32 rows (8 chunks per lane); the residual rows of pass p + 1 are requested before the stores of pass p go out
         f32x4 rv[8];
         auto load_res = [&](int pass) {
-            const float* rp = g.R + (size_t)(bm + wm * 128 + pass * 32 + r4) * g.ldr + ncol;
+            const float* rp = Rp + (size_t)(bm + wm * 128 + pass * 32 + r4) * g.ldr + ncol;
 #pragma unroll
             for (int it = 0; it < 8; ++it) rv[it] = *reinterpret_cast<const f32x4*>(rp + (size_t)(it * 4) * g.ldr);
         };
-        if (whole && g.R) load_res(0);
+        if (whole && Rp) load_res(0);
+        f32x4 yv[LNF ? 4 : 1][8];                                     // LNF: the wave's 128 x 64 sums stay in registers until the row moments are known
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -283,19 +310,24 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
                     f32x4 v[8];
 #pragma unroll
                     for (int it = 0; it < 8; ++it) { const int row = hb * 32 + it * 4 + r4; v[it] = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ (row & 15)) * 16)); }
-                    if (g.R) {
+                    if (Rp) {
 #pragma unroll
                         for (int it = 0; it < 8; ++it) { v[it].x += rv[it].x; v[it].y += rv[it].y; v[it].z += rv[it].z; v[it].w += rv[it].w; }
                         if (pass < 3) load_res(pass + 1);
                     }
+                    if constexpr (LNF) {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) yv[pass][it] = v[it];
+                    } else {
                     const size_t m0 = (size_t)(bm + wm * 128 + pass * 32 + r4);
-                    float* cp = g.C + m0 * g.ldc + ncol;
+                    float* cp = Cp + m0 * g.ldc + ncol;
 #pragma unroll
                     for (int it = 0; it < 8; ++it) *reinterpret_cast<f32x4*>(cp + (size_t)(it * 4) * g.ldc) = v[it];
                     if (g.Cb) {
                         bf16_t* cb = g.Cb + m0 * g.ldcb + ncol;
 #pragma unroll
                         for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x2*>(cb + (size_t)(it * 4) * g.ldcb) = pack4<HT>(v[it]);
+                    }
                     }
                 }
             } else {
@@ -306,15 +338,15 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
                 f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
                 const size_t mr = (size_t)(g.r_mod > 0 ? m % g.r_mod : m), mo = g.cmap(m);
                 if (ncol + 3 < g.N) {
-                    if (g.R) { const f32x4 r4v = *reinterpret_cast<const f32x4*>(g.R + mr * g.ldr + ncol); v.x += r4v.x; v.y += r4v.y; v.z += r4v.z; v.w += r4v.w; }
-                    *reinterpret_cast<f32x4*>(g.C + mo * g.ldc + ncol) = v;
+                    if (Rp) { const f32x4 r4v = *reinterpret_cast<const f32x4*>(Rp + mr * g.ldr + ncol); v.x += r4v.x; v.y += r4v.y; v.z += r4v.z; v.w += r4v.w; }
+                    *reinterpret_cast<f32x4*>(Cp + mo * g.ldc + ncol) = v;
                     if (g.Cb) *reinterpret_cast<u32x2*>(g.Cb + mo * g.ldcb + ncol) = pack4<HT>(v);
                 } else {
                     const float vv[4] = {v.x, v.y, v.z, v.w};
                     for (int r = 0; r < 4 && ncol + r < g.N; ++r) {
                         float tt = vv[r];
-                        if (g.R) tt += g.R[mr * g.ldr + ncol + r];
-                        g.C[mo * g.ldc + ncol + r] = tt;
+                        if (Rp) tt += Rp[mr * g.ldr + ncol + r];
+                        Cp[mo * g.ldc + ncol + r] = tt;
                         if (g.Cb) g.Cb[mo * g.ldcb + ncol + r] = H16<HT>::bits(tt);
                     }
                 }
@@ -322,6 +354,81 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
             }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the patch is re-written for the second half
+        }
+        if constexpr (LNF) {
+            // (the launcher sends whole tiles only: `whole` holds for every workgroup of an LNF launch)
+            float* lsum = reinterpret_cast<float*>(g256_smem + G256_LDS);      // [4][256]
+            float* lmean = lsum + 1024; float* lrstd = lmean + 256;
+            const int rloc = wm * 128 + r4;                               // block-local row of (pass 0, it 0) of this lane
+            const size_t tiles_all = (size_t)nty * ntx;
+            u64* const gs = ln.gran + (size_t)tile_y * ntx * 256;        // this tile row's granules: [tile_x][256]
+            u64* const gq = gs + tiles_all * 256;
+            // the two rounds share their second half: add the four waves' partial sums, publish, gather the other tiles' in ascending order
+            auto exchange = [&](u64* gr) -> float {
+                const float mine = (lsum[tid] + lsum[256 + tid]) + (lsum[512 + tid] + lsum[768 + tid]);
+                ps_publish(gr + (size_t)tile_x * 256, tid, ln.epoch, __float_as_uint(mine));
+                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                float tot = 0.f;
+                for (int tx = 0; tx < ntx; ++tx) {
+                    float val = mine;
+                    if (tx != tile_x) {
+                        const gu64* pp = (const gu64*)(gr + (size_t)tx * 256) + tid;
+                        for (;;) {
+                            const u64 v = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(v >> 32) == ln.epoch) { val = __uint_as_float((unsigned)v); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            if (xchg_expired(spins, t0, ln.err)) { xchg_raise(ln.err, G256_ERR_LN, spins); val = 0.f; break; }
+                        }
+                    }
+                    tot += val;
+                }
+                return tot;
+            };
+            // ---- round 1: row sums -> mean
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const f32x4 y = yv[pass][it];
+                    const float sw = row_sum16((y.x + y.y) + (y.z + y.w));
+                    if (c == 0) lsum[wn * 256 + rloc + pass * 32 + it * 4] = sw;
+                }
+            __syncthreads();
+            if (tid < 256) lmean[tid] = exchange(gs) / (float)g.N;
+            __syncthreads();
+            // ---- round 2: sums of squared deviations -> rstd  (yv <- y - mean)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float mu = lmean[rloc + pass * 32 + it * 4];
+                    f32x4 d = yv[pass][it];
+                    d.x -= mu; d.y -= mu; d.z -= mu; d.w -= mu;
+                    yv[pass][it] = d;
+                    const float qw = row_sum16((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
+                    if (c == 0) lsum[wn * 256 + rloc + pass * 32 + it * 4] = qw;
+                }
+            __syncthreads();
+            if (tid < 256) lrstd[tid] = 1.0f / sqrtf(exchange(gq) / (float)g.N + ln.eps);
+            __syncthreads();
+            // ---- normalise this tile's columns: h (fp32, over the residual this workgroup read) and its 16-bit copy
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(ln.gamma + ncol), be = *reinterpret_cast<const f32x4*>(ln.beta + ncol);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const size_t m0 = (size_t)(bm + wm * 128 + pass * 32 + r4);
+                float* cp = Cp + m0 * g.ldc + ncol;
+                bf16_t* cb = g.Cb ? g.Cb + m0 * g.ldcb + ncol : nullptr;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float rs = lrstd[rloc + pass * 32 + it * 4];
+                    const f32x4 d = yv[pass][it];
+                    f32x4 o;
+                    o.x = d.x * rs * ga.x + be.x; o.y = d.y * rs * ga.y + be.y; o.z = d.z * rs * ga.z + be.z; o.w = d.w * rs * ga.w + be.w;
+                    *reinterpret_cast<f32x4*>(cp + (size_t)(it * 4) * g.ldc) = o;
+                    if (cb) *reinterpret_cast<u32x2*>(cb + (size_t)(it * 4) * g.ldcb) = pack4<HT>(o);
+                }
+            }
         }
     }
     if (trace && tid == 0) trace[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -578,6 +685,19 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256p_kernel(GemmTArgs g, i
 #undef G256_COMPUTE
 }
 
+// the LNF form of the one-tile kernel (LayerNorm finished in the epilogue)
+template <typename HT>
+inline hipError_t g256_launch_ln(const GemmTArgs& g, int nty, int ntx, hipStream_t s, const G256Ln& ln) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<HT, ACT_NONE, 0, G256_EV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS + G256_LN_LDS);
+        if (r != hipSuccess) return r;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm256_kernel<HT, ACT_NONE, 0, G256_EV, true>), dim3(nty * ntx), dim3(512), G256_LDS + G256_LN_LDS, s, g, nty, ntx, (unsigned long long*)nullptr, 1, 0L, ln);
+    return hipGetLastError();
+}
+
 template <typename HT, int ACT, bool KV = false>
 inline hipError_t g256p_launch(const GemmTArgs& g, int nty, int ntx, int n_cus, hipStream_t s) {
     static bool attr = false;
@@ -592,14 +712,14 @@ inline hipError_t g256p_launch(const GemmTArgs& g, int nty, int ntx, int n_cus, 
 }
 
 template <typename HT, int ACT>
-inline hipError_t g256_launch(const GemmTArgs& g, int nty, int ntx, hipStream_t s) {
+inline hipError_t g256_launch(const GemmTArgs& g, int nty, int ntx, hipStream_t s, int ks = 1, long part_stride = 0) {
     static bool attr = false;
     if (!attr) {
         hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<HT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS);
         if (r != hipSuccess) return r;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm256_kernel<HT, ACT>), dim3(nty * ntx), dim3(512), G256_LDS, s, g, nty, ntx, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL((gemm256_kernel<HT, ACT>), dim3(nty * ntx * ks), dim3(512), G256_LDS, s, g, nty, ntx, (unsigned long long*)nullptr, ks, part_stride);
     return hipGetLastError();
 }
 
@@ -618,9 +738,31 @@ inline int g256_gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = 
 
 // kv_rows (optional): with GemmTArgs::kv_k set, the number of leading rows whose K / V columns went to the cache planes (0: none -- the caller fills
 // the cache from the output tensor, as it does for the rows behind that count)
+// sk (optional): the caller can take the fp32 output as up to `max_parts` partial sums along K (buffers g.C + p * part_stride, to be added up by the
+// consumer: ln_rows2_kernel's KS form): used when K is long and the 256 x 256 tiles would fill well under a round of the chip.  On return `parts` (1: not
+// split) and `rows` = the leading rows that ARE split (the tail rows behind them are complete in part 0).
+struct GemmSplitK { int max_parts = 1; long part_stride = 0; int parts = 1; int rows = 0; };
+// lnf (optional): the caller wants LayerNorm(gamma, beta, eps) of the fp32 result instead of the result: C <- LN(A W^T + bias + R) (may be in place over R),
+// Cb its 16-bit copy.  On return `rows` = the leading rows for which the GEMM did it (the one-tile kernel's LNF form; 0: none) -- the caller runs the
+// row kernel over the rows behind them, whose plain sums were written to `tail_c` (same leading dimension as C) instead of C.
+struct GemmLnFuse { G256Ln ln; float* tail_c = nullptr; int rows = 0; };
+template <typename HT> inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_ln, int n_cus, hipStream_t s, int* kv_rows, GemmSplitK* sk, GemmLnFuse* lnf);
 template <typename HT>
-inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s, int* kv_rows = nullptr) {
+inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s, int* kv_rows = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr) {
+    if (lnf && lnf->tail_c) {
+        // every launch that does NOT finish the LayerNorm writes plain sums to the caller's tail buffer and no 16-bit copy (the caller's row kernel follows)
+        GemmTArgs plain = g;
+        plain.C = lnf->tail_c; plain.Cb = nullptr;
+        return launch_gemm_dense_impl<HT>(plain, g, n_cus, s, kv_rows, sk, lnf);
+    }
+    return launch_gemm_dense_impl<HT>(g, g, n_cus, s, kv_rows, sk, nullptr);
+}
+// g: the arguments of the plain launches; g_ln: those of the LNF launch (outputs = the LayerNorm's)
+template <typename HT>
+inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_ln, int n_cus, hipStream_t s, int* kv_rows, GemmSplitK* sk, GemmLnFuse* lnf) {
     if (kv_rows) *kv_rows = 0;
+    if (sk) { sk->parts = 1; sk->rows = 0; }
+    if (lnf) lnf->rows = 0;
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
     // the 256-row tile's 16-bit-only epilogue (C == nullptr) carries no residual and stores 16 bytes to Cb: such calls take the 128-row tile
@@ -633,7 +775,17 @@ inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s
         //  TFLOP/s, 192 tiles = 0.75 round 911 vs ~450; profiles/r06_ubench_gemm256p.txt, r06_calib_library_gemm.txt)
         auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles * 100 >= rounds * n_cus * 60; };
         int nty = 0;                                                 // tile rows on the big tile
-        if (!can_split) { if (fills((long)ntx * ((g.M + 255) / 256))) nty = (g.M + 255) / 256; }      // ragged last tile row computed with clamped rows
+        int ks = 1;
+        if (sk && sk->max_parts >= 2 && gemm256_enabled() >= 2 && can_split && g.C && !g.Cb && g.act == ACT_NONE && g.N % 256 == 0 && g.K >= 2048 && !fills((long)ntx * (g.M / 256)) &&
+            (long)ntx * (g.M / 256) >= 8) {
+            // few tiles, long K: 4 (or 2) parts along K so that the launch comes to about one round (fc2 at 16 samples: 64 tiles x 4 = one round of 16 K-tiles
+            // instead of a quarter round of 64)
+            const long tiles = (long)ntx * (g.M / 256);
+            ks = (sk->max_parts >= 4 && tiles * 4 <= n_cus + n_cus / 8 && g.K % 256 == 0) ? 4 : ((tiles * 2 <= n_cus + n_cus / 8 && g.K % 128 == 0) ? 2 : 1);
+            if (ks > 1) nty = g.M / 256;
+        }
+        if (ks > 1) {}
+        else if (!can_split) { if (fills((long)ntx * ((g.M + 255) / 256))) nty = (g.M + 255) / 256; }      // ragged last tile row computed with clamped rows
         else if (fills((long)ntx * (g.M / 256))) nty = g.M / 256;
         else { const int q = n_cus / g256_gcd(ntx, n_cus); nty = g.M / 256 / q * q; }
         if (nty > 0) {
@@ -642,31 +794,56 @@ inline hipError_t launch_gemm_dense(const GemmTArgs& g, int n_cus, hipStream_t s
             // whole tiles with 16-bit output: the persistent form (next tile's operands requested before this tile's epilogue; its 4-KB-patch epilogue is
             // the faster one even where every workgroup has a single tile)
             const bool persist = gemm256_enabled() >= 2 && can_split && !g.C && g.Cb && !g.R && g.N % 256 == 0 && n_cus >= 8;
-            const bool kv = persist && kv_rows && g.kv_k && g.kv_v && g.act == ACT_NONE && g.kv_T >= 8 && g.kv_col0 % 64 == 0 && g.N == 3 * g.kv_col0;
+            // (measured and not kept, round 6: at 64 samples out_proj / fc2 with the LayerNorm inside took 79 / 158 us against 42 + 30 / 124 + 30 us for GEMM +
+            //  row kernel -- the epilogue holds the 128 x 64 sums of a wave in registers across two exchanges (97 dwords per lane spilled) and every tile row
+            //  waits for its slowest tile twice; profiles/r06_ab_layernorm_in_gemm.txt.  Compiled with MA_EXPERIMENTAL=1 only.)
+#ifdef MA_EXPERIMENTAL
+            const bool do_ln = lnf && ks == 1 && gemm256_enabled() >= 2 && can_split && g.C && g.act == ACT_NONE && g.N % 256 == 0 && lnf->ln.gran && lnf->ln.gamma && lnf->ln.beta &&
+                               lnf->ln.err && lnf->ln.epoch != 0 && g_ln.C && g_ln.ldc % 4 == 0 && (!g_ln.Cb || g_ln.ldcb % 4 == 0);
+            if (do_ln) {
+                lnf->rows = nty * 256;
+                GemmTArgs ml = g_ln;
+                ml.M = nty * 256;
+                hipError_t r = g256_launch_ln<HT>(ml, nty, ntx, s, lnf->ln);
+                if (r != hipSuccess) return r;
+            }
+#else
+            const bool do_ln = false;
+            (void)g_ln;
+#endif
+            if (ks > 1) {
+                sk->parts = ks; sk->rows = nty * 256;
+                hipError_t r = g256_launch<HT, ACT_NONE>(m, nty, ntx, s, ks, sk->part_stride);
+                if (r != hipSuccess) return r;
+            }
+            const bool kv = ks == 1 && persist && kv_rows && g.kv_k && g.kv_v && g.act == ACT_NONE && g.kv_T >= 8 && g.kv_col0 % 64 == 0 && g.N == 3 * g.kv_col0;
             if (kv) {
                 *kv_rows = nty * 256;
                 hipError_t r = g256p_launch<HT, ACT_NONE, true>(m, nty, ntx, n_cus, s);
                 if (r != hipSuccess) return r;
             }
-            hipError_t r = kv ? hipSuccess : persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
+            hipError_t r = (kv || ks > 1 || do_ln) ? hipSuccess : persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
                                                                                                                              : g256p_launch<HT, ACT_NONE>(m, nty, ntx, n_cus, s))
                                    : (g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s));
             const int rest = can_split ? g.M - nty * 256 : 0;
             if (r != hipSuccess || rest == 0) return r;
             const size_t r0 = (size_t)nty * 256;
+            // (with lnf: g.C is the caller's tail buffer and g.Cb null -- the rows behind the tiles leave as plain sums, their LayerNorm is the caller's row kernel)
+            float* const tailC = g.C;
+            bf16_t* const tailCb = g.Cb;
             if (rest <= 64 && g.K % 128 == 0) {
                 GemmDecArgs d{};
                 d.W = g.W; d.bias = g.bias; d.xb = g.A + r0 * g.lda; d.xb_stride = g.lda; d.N = g.N; d.K = g.K; d.B = rest; d.act = g.act; d.epi = EPI_PLAIN; d.ksplit = 1;
                 if (g.R) { d.res = g.R + r0 * g.ldr; d.res_stride = g.ldr; }
-                if (g.C) { d.y = g.C + r0 * g.ldc; d.y_stride = g.ldc; }
-                if (g.Cb) { d.yb = g.Cb + r0 * g.ldcb; d.yb_stride = g.ldcb; }
+                if (tailC) { d.y = tailC + r0 * g.ldc; d.y_stride = g.ldc; }
+                if (tailCb) { d.yb = tailCb + r0 * g.ldcb; d.yb_stride = g.ldcb; }
                 return launch_gemm_dec<HT>(d, s);
             }
             GemmTArgs t = g;
             t.A = g.A + r0 * g.lda; t.M = rest;
             if (g.R) t.R = g.R + r0 * g.ldr;
-            if (g.C) t.C = g.C + r0 * g.ldc;
-            if (g.Cb) t.Cb = g.Cb + r0 * g.ldcb;
+            t.C = tailC ? tailC + r0 * g.ldc : nullptr;
+            t.Cb = tailCb ? tailCb + r0 * g.ldcb : nullptr;
             return launch_gemm_tile<HT>(t, s);
         }
     }

@@ -37,6 +37,30 @@ for st in $STAGES; do
       timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider -k "gemm" -s 2>&1 | grep -v amdgpu.ids > $O/gemmtests.txt; grep -E "gemm256|passed|failed|Error" $O/gemmtests.txt | cut -c1-330 | tail -40 ;;
     stress)
       timeout 900 python scripts/stress_gemm256.py ${STRESS_N:-600} 2>&1 | grep -v amdgpu.ids > $O/stress_gemm256.txt; tail -30 $O/stress_gemm256.txt ;;
+    soak)
+      # the form in which round 5's one fall-back was seen, then the vector-sweep control
+      timeout 1500 python scripts/stress_rows_b8.py ${SOAK_N:-30} 1600 forced 6 2>&1 | grep -v amdgpu.ids > $O/soak_rows_b8_forced_early6.txt; tail -4 $O/soak_rows_b8_forced_early6.txt
+      timeout 1500 python scripts/stress_rows_b8.py ${SOAK_N:-30} 1600 forced 3 2>&1 | grep -v amdgpu.ids > $O/soak_rows_b8_forced_early3.txt; tail -4 $O/soak_rows_b8_forced_early3.txt ;;
+    pmc)
+      # PMC passes (separate runs, --kernel-trace only, as the MI355X guide prescribes): HBM bytes of the decode launches, matrix-core busy of the dense phases
+      cd /tmp
+      for C in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pmc_$C
+        timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o p --output-format csv -- python $R/scripts/prof_step.py --options "use_graph=0" --steps 2 --gen 96 > $O/pmc_$C.log 2>&1
+      done
+      python $R/scripts/pmc_summary.py $O/r06_pmc_decode_raw.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $O/pmc_decode_summary.log 2>&1
+      rm -rf /tmp/pmc_mfma
+      timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- python $R/scripts/prof_dense.py --batches 64 --iters 1 > $O/pmc_mfma.log 2>&1
+      python $R/scripts/pmc_summary.py $O/r06_pmc_dense_mfma_raw.json /tmp/pmc_mfma > $O/pmc_mfma_summary.log 2>&1
+      python $R/scripts/pmc_r2_report.py $O/r06_pmc_decode_raw.json $O/r06_pmc_dense_mfma_raw.json $O r06
+      head -c 600 $O/r06_pmc_decode_traffic.json; echo; python - <<PY
+import json
+d = json.load(open("$O/r06_pmc_dense_mfma.json"))
+print({k: v for k, v in d.items() if k != "per_kernel" and k != "formula" and k != "source"})
+for k, v in sorted(d["per_kernel"].items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"] * kv[1]["dispatches"])[:14]:
+    print(f"{v['mfma_busy_frac']:.3f} x{v['dispatches']:4d}  {k[:110]}")
+PY
+      cd $R ;;
     *) echo "unknown stage $st" ;;
   esac
 done

@@ -44,7 +44,7 @@ for k, cs in den.items():
         continue
     rows[k] = {"dispatches": mf["dispatches"], "SQ_VALU_MFMA_BUSY_CYCLES": round(mf["mean"], 1), "GRBM_GUI_ACTIVE": round(ga["mean"], 1),
                "mfma_busy_frac": round(mf["mean"] / (ga["mean"] / 8.0 * 1024), 4)}
-DENSE = ("gemm_tile", "gemm256", "gemm_dec", "gemm_mfma_f32", "attention", "vt_pack", "ln_rows2", "kv_fill2", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")
+DENSE = ("gemm_tile", "gemm256", "gemm_dec", "gemm_mfma_f32", "attention", "vt_pack", "ln_rows2", "kv_fill2", "kv_fill_rows", "cvt_rows", "add_rows2", "codes_gather2", "fourier2", "coords_argmax")
 def is_f32(k):                       # kernels of the exact (fp32) point encoder: fp32 matrix path, fp32 attention, fp32 row kernels
     return "gemm_mfma_f32" in k or "attention_f32" in k or ("<float>" in k and "unsigned short" not in k and "_Float16" not in k)
 def busy(pred):

@@ -665,3 +665,78 @@ def test_prefill_kv_written_by_the_qkv_gemm_equals_the_copy(golden_dir, policy):
     finally:
         eng.set_option("qkv_to_cache", 1); eng.set_option("gemm256", 2)
     eng.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp16"])
+def test_prefill_of_16_samples_with_fc2_split_along_k(golden_dir, policy):
+    """Round 6: at 16 samples (M = 4 112) the prefill's fc2 -- N = 1024: 64 tiles of 256 x 256, each 64 K-tiles deep -- runs as FOUR partial sums along
+    K (csrc/gemm256.hpp, GemmSplitK) that the LayerNorm behind it adds up (ln_rows2_kernel, KS form); q|k|v takes the persistent tiles at 0.75 round.
+    The summation order along K differs from the unsplit kernel's, so the two are compared the way every 16-bit path is: each against the oracle along
+    its own greedy stream, and against each other on the logits of the same forced stream."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle
+    B, n = 16, 12
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=B)
+    env = Env.__new__(Env)
+    env.cfg, env.policy = cfg, policy
+    env.sd = cached_state_dict(cfg, init=FULL_INIT)
+    env.oracle = Oracle(cfg, env.sd, policy, device=oracle_device())
+    env.engine = eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=FULL_INIT)
+    x = mouse_variants(golden_dir, B)
+    prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
+    assert eng.get_option("gemm_splitk") == 1
+    try:
+        toks, lengths, lg = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
+        v = _check_greedy(env, prefix, toks, lengths, suppress_eos=True)
+        assert all(r["ambiguous"] <= 2 for r in v), [r["ambiguous"] for r in v]
+        eng.set_option("gemm_splitk", 0)
+        t0, _, lg0 = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, forced_tokens=toks, return_logits=True)
+        err = float((lg - lg0).abs().max())
+        same = float((t0 == toks).float().mean())
+        print(f"[{policy}] 16-sample prefill, fc2 as 4 partial sums along K vs unsplit: max abs logit difference over {n} steps x {B} rows {err:.5f}, same picks {same * 100:.1f} %")
+        assert err <= {"bf16": 3e-2, "fp16": 4e-3}[policy] and same >= 0.9
+    finally:
+        eng.set_option("gemm_splitk", 1)
+    eng.close()
+
+
+@pytest.mark.parametrize("policy", ["bf16", "fp16"])
+def test_prefill_layernorm_finished_inside_the_gemm(golden_dir, policy):
+    """Round 6 (measured, not kept; MA_EXPERIMENTAL=1 builds): at 64 samples the prefill's out_proj and fc2 (N = hidden: four 256 x 256 tiles per tile row) finish the LayerNorm that follows them in
+    their own epilogue -- the four workgroups of a tile row exchange per-row moments through {epoch, value} granules (csrc/gemm256.hpp, LNF form) -- and the
+    row kernel only handles the 64-row tail.  The moments are the row kernel's two-pass form summed in another (fixed) order, so the two paths are compared
+    like every 16-bit path: rows of the batch against the oracle along their own greedy stream, both paths on the logits of the same forced stream, and the
+    fused path against itself (its result must not depend on which workgroup publishes first)."""
+    from meshanything_amd.engine import Engine
+    from oracle.meshanything_oracle import Oracle, verify_greedy_stream
+    B, n = 64, 10
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=B)
+    sd = cached_state_dict(cfg, init=FULL_INIT)
+    oracle = Oracle(cfg, sd, policy, device=oracle_device())
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=FULL_INIT)
+    x = mouse_variants(golden_dir, B)
+    prefix = torch.cat([oracle.process_point_feature(oracle.encode_latents(x[i:i + 16])) for i in range(0, B, 16)])
+    if not eng.get_option("experimental"):
+        pytest.skip("LayerNorm inside the GEMM epilogue was measured and not kept: MA_EXPERIMENTAL=1 builds only (profiles/r06_ab_layernorm_in_gemm.txt)")
+    eng.set_option("fuse_ln", 1)
+    if eng.get_option("fuse_ln") != 1:
+        pytest.skip("the in-launch exchanges are not in use on this device")
+    try:
+        with fused_path_must_hold(eng, f"{policy} prefill with fused LayerNorm"):
+            toks, lengths, lg = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
+            t2, _, lg2 = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
+        assert torch.equal(toks, t2) and torch.equal(lg.view(torch.int32), lg2.view(torch.int32)), "the fused LayerNorm is not bit-stable from launch to launch"
+        for b in (0, 21, 42, 63):                                    # (63: its last 64 rows are the tail the row kernel normalises)
+            v = verify_greedy_stream(oracle, prefix[b:b + 1], toks[b, :int(lengths[b])].cpu(), GREEDY_TOL[policy], True)
+            assert v["hard"] == [] and v["ambiguous"] <= 2, (b, v)
+        eng.set_option("fuse_ln", 0)
+        t0, _, lg0 = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, forced_tokens=toks, return_logits=True)
+        err = float((lg - lg0).abs().max())
+        same = float((t0 == toks).float().mean())
+        print(f"[{policy}] 64-sample prefill, LayerNorm inside out_proj / fc2 vs the row kernel: max abs logit difference over {n} steps x {B} rows {err:.5f}, same picks {same * 100:.1f} %")
+        assert err <= {"bf16": 3e-2, "fp16": 4e-3}[policy] and same >= 0.9
+    finally:
+        eng.set_option("fuse_ln", 0)
+    eng.close()
