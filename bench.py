@@ -373,17 +373,17 @@ def main():
         dc = classes[dom]
         step_ms = prof["step_ms_graph"] or prof["step_ms_eager"]
         step_bytes = wbytes + kvbytes
-        # HBM bytes per launch of the dominant class from the PMC counters (scripts/gpu_pmc_r2.sh: separate rocprofv3 --pmc passes,
+        # HBM bytes per launch of the dominant class from the PMC counters (scripts/gpu_r6.sh, stage pmc: separate rocprofv3 --pmc passes,
         # corrected as the MI355X guide prescribes; committed under profiles/): None when no such file is present
         # (a --pmc pass cannot run inside this process: the figure is IMPORTED from the committed profile of the same kernels and labelled so)
         traffic, traffic_source = None, None
-        for name in ("r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
+        for name in ("r06_pmc_decode_traffic.json", "r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json"):
             f = os.path.join(REPO, "profiles", name)
             if traffic is None and os.path.exists(f) and args.batch == 1 and args.dtype == "bf16" and args.faces == 800:
                 traffic = json.load(open(f)).get("hbm_bytes_per_launch", {}).get(dom)
                 if traffic is not None:
                     traffic_source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; imported, NOT measured by this run)"
-        # 8 rows: the PMC pass of the two fused launches at THIS cache length (profile_decode steps only, scripts/gpu_pmc_b8_mid.sh)
+        # 8 rows: the PMC pass of the two fused launches at THIS cache length (profile_decode steps only, scripts/archive/gpu_pmc_b8_mid.sh)
         f8 = os.path.join(REPO, "profiles", "r05_pmc_decode_traffic_b8_kv3858.json")
         if traffic is None and rows_attn and rows_mlp and args.dtype == "bf16" and mid == 3858 and os.path.exists(f8):
             traffic = json.load(open(f8)).get("hbm_bytes_per_launch", {}).get(dom)

@@ -172,21 +172,35 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a
             }
         }
         // ---- online softmax on the lane's 32 keys of its query: key = 64 t + 32 kbk + (i & 3) + 8 (i >> 2) + 4 hi ----------------------
+        // (round 6: the softmax's vector arithmetic, not the matrix pipe, set this kernel's pace -- ~300 vector instructions against 16 MFMAs per tile and
+        //  wave, matrix cores 0.12 - 0.32 busy.  Three cuts: tiles that lie wholly below every row's last visible key skip the mask (a wave-uniform test:
+        //  all but the last tile of an unmasked sequence, all but the diagonal tiles of a causal one); the scale rides in the exponent's fused multiply-add
+        //  (scores stay raw, the running maximum is kept in the scaled domain: one multiply per tile instead of 32); the output accumulators are rescaled
+        //  only when some row's maximum moved.)
         const int kbase = (t << 6) + 4 * hi;
-        const int klimit = a.causal_offset >= 0 ? min(a.Sk - 1, a.causal_offset + qrow) : a.Sk - 1;       // last visible key
+        const int klimit = a.causal_offset >= 0 ? min(a.Sk - 1, a.causal_offset + qrow) : a.Sk - 1;       // last visible key of this lane's query
+        const int klimit_wave = a.causal_offset >= 0 ? min(a.Sk - 1, a.causal_offset + q0 + w * 32) : a.Sk - 1;      // ... of the wave's first row: the smallest
         float mx = -INFINITY;
+        if ((t << 6) + 63 <= klimit_wave) {
 #pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
+            for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kbase + 32 * kbk + (i & 3) + 8 * (i >> 2);
-                const float v = key <= klimit ? sacc[kbk][i] * sc2 : -INFINITY;
-                sacc[kbk][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                         // the partner lane holds the query's other 32 keys
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kbk][i]);
+        } else {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kbase + 32 * kbk + (i & 3) + 8 * (i >> 2);
+                    const float v = key <= klimit ? sacc[kbk][i] : -INFINITY;
+                    sacc[kbk][i] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc2;                   // the partner lane holds the query's other 32 keys; sc2 > 0: the maximum commutes with the scale
         const float mnew = fmaxf(mrun, mx);
         const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        const bool moved = mnew != mrun;
         mrun = mnew;
         float ps = 0.f;
         u32x4 pf[4];                                                    // P^T as B fragments: slice s = keys 16 s .. 16 s + 15 of the tile
@@ -195,16 +209,18 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_mfma2_kernel(Attn2Args a
             uint32_t w4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e0 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j] - mnew);        // exp2(-inf) = 0: masked keys drop out
-                const float e1 = __builtin_amdgcn_exp2f(sacc[s >> 1][8 * (s & 1) + 2 * j + 1] - mnew);
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[s >> 1][8 * (s & 1) + 2 * j], sc2, -mnew));        // exp2(-inf) = 0: masked keys drop out
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[s >> 1][8 * (s & 1) + 2 * j + 1], sc2, -mnew));
                 ps += e0 + e1;
                 w4[j] = a2_pack<HT>(e0, e1);
             }
             pf[s] = u32x4{w4[0], w4[1], w4[2], w4[3]};
         }
-        lsum = lsum * alpha + ps;
+        if (__any(moved)) {                                             // (alpha == 1 exactly for every row otherwise)
+            lsum = lsum * alpha + ps;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        } else lsum += ps;
         // ---- O^T += V^T P^T: four 16-key slices x two 32-row d blocks ------------------------------------------------------------------
 #pragma unroll
         for (int db = 0; db < 2; ++db) {

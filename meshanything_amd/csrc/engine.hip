@@ -1128,7 +1128,7 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
             attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
                       (size_t)T * 3 * H, (size_t)T * H);
         }
-        gemm_res_ln(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, false);
+        gemm_res_ln(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, e->opt_gemm_splitk >= 2);
         gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU);
         // small batches: fc2's 256 x 256 tiles (N = hidden: four per tile row) fill a fraction of the chip while each runs 64 K-tiles -- split along K
         // into partial sums that the LayerNorm adds up (gemm256.hpp GemmSplitK; 16 samples: 64 tiles x 4 parts = one round of 16 K-tiles)
@@ -1623,7 +1623,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "qkv_to_cache") e->opt_qkv_to_cache = value ? 1 : 0;
-        else if (n == "gemm_splitk") e->opt_gemm_splitk = value ? 1 : 0;
+        else if (n == "gemm_splitk") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "gemm_splitk: 0 (never), 1 (fc2 of small prefills), 2 (+ out_proj)"); e->opt_gemm_splitk = (int)value; }
         else if (n == "fuse_ln") {
 #ifndef MA_EXPERIMENTAL
             if (value) throw MaError(MA_ERR_STATE, "fuse_ln needs a library built with MA_EXPERIMENTAL=1 (LayerNorm inside the GEMM epilogue: measured, not kept)");

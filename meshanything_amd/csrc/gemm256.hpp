@@ -776,7 +776,7 @@ inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_
         auto fills = [&](long tiles) { const long rounds = (tiles + n_cus - 1) / n_cus; return tiles * 100 >= rounds * n_cus * 60; };
         int nty = 0;                                                 // tile rows on the big tile
         int ks = 1;
-        if (sk && sk->max_parts >= 2 && gemm256_enabled() >= 2 && can_split && g.C && !g.Cb && g.act == ACT_NONE && g.N % 256 == 0 && g.K >= 2048 && !fills((long)ntx * (g.M / 256)) &&
+        if (sk && sk->max_parts >= 2 && gemm256_enabled() >= 2 && can_split && g.C && !g.Cb && g.act == ACT_NONE && g.N % 256 == 0 && g.K >= 1024 && !fills((long)ntx * (g.M / 256)) &&
             (long)ntx * (g.M / 256) >= 8) {
             // few tiles, long K: 4 (or 2) parts along K so that the launch comes to about one round (fc2 at 16 samples: 64 tiles x 4 = one round of 16 K-tiles
             // instead of a quarter round of 64)
@@ -786,8 +786,22 @@ inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_
         }
         if (ks > 1) {}
         else if (!can_split) { if (fills((long)ntx * ((g.M + 255) / 256))) nty = (g.M + 255) / 256; }      // ragged last tile row computed with clamped rows
-        else if (fills((long)ntx * (g.M / 256))) nty = g.M / 256;
-        else { const int q = n_cus / g256_gcd(ntx, n_cus); nty = g.M / 256 / q * q; }
+        else {
+            // all whole tile rows (when their rounds are reasonably full), or the largest count that makes EXACT rounds with the remaining rows on the 128-row
+            // tiles -- whichever the estimate below puts first.  (The detokenizer at 64 samples: 264 tile rows x 3 tiles = 3.09 rounds; the fourth round
+            // cost a whole tile time, 33 - 88 us, for 24 tiles, where the 2 112 remaining rows take 10 - 35 us on the small tiles.)
+            const int nty_full = fills((long)ntx * (g.M / 256)) ? g.M / 256 : 0;
+            const int q = n_cus / g256_gcd(ntx, n_cus), nty_exact = g.M / 256 / q * q;
+            auto cost_us = [&](int n) -> double {
+                if (n <= 0) return 1e30;
+                const double t_tile = (g.K / 64) * 1.5 + (g.C ? 12.0 : 5.0) + 3.0;
+                const long rounds = ((long)n * ntx + n_cus - 1) / n_cus;
+                const long rest = g.M - (long)n * 256;
+                const double t_rest = rest == 0 ? 0.0 : (rest <= 64 ? 11.0 : 15.0 + 2.0 * (double)rest * g.N * g.K / 2.5e8);      // (measured: 2 176 rows x 768 x 768 / 3072 on the small tiles 19 - 50 us)
+                return rounds * t_tile + t_rest;
+            };
+            nty = cost_us(nty_exact) < cost_us(nty_full) ? nty_exact : nty_full;
+        }
         if (nty > 0) {
             GemmTArgs m = g;
             m.M = can_split ? nty * 256 : g.M;

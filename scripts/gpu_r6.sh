@@ -61,6 +61,23 @@ for k, v in sorted(d["per_kernel"].items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_
     print(f"{v['mfma_busy_frac']:.3f} x{v['dispatches']:4d}  {k[:110]}")
 PY
       cd $R ;;
+    phase)
+      # kernel trace of ONE dense phase ($PHASE = prefill | detok) at $PB samples
+      cd /tmp; rm -rf /tmp/prof_p
+      timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o d --output-format csv -- python $R/scripts/prof_dense.py --batches ${PB:-64} --iters 3 --phases ${PHASE:-detok} > $O/prof_${PHASE:-detok}_rocprof.log 2>&1
+      for f in $(find /tmp/prof_p -name "*kernel_stats*.csv"); do cp $f $O/${PHASE:-detok}_b${PB:-64}_kernel_stats.csv; done
+      grep dense $O/prof_${PHASE:-detok}_rocprof.log; head -24 $O/${PHASE:-detok}_b${PB:-64}_kernel_stats.csv | cut -d, -f1-4 | cut -c1-170; cd $R ;;
+    benchprof)
+      # the kernel trace of the bench command itself (roofline.avg_launch_us must agree with it) and of the 8-row workload
+      cd /tmp; rm -rf /tmp/prof_b /tmp/prof_b8
+      timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batched-table > $O/bench_profiled.json 2> $O/bench_profiled.err
+      for f in $(find /tmp/prof_b -name "*kernel_stats*.csv"); do cp $f $O/bench_kernel_stats.csv; done
+      head -6 $O/bench_kernel_stats.csv | cut -c1-200
+      timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_b8 -o b --output-format csv -- python $R/bench.py --batch 8 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_b8_profiled.json 2> $O/bench_b8_profiled.err
+      for f in $(find /tmp/prof_b8 -name "*kernel_stats*.csv"); do cp $f $O/bench_batch8_kernel_stats.csv; done
+      head -5 $O/bench_batch8_kernel_stats.csv | cut -c1-200; cd $R ;;
+    cfg3)
+      timeout 900 python bench.py --batch 64 --sampling --steps 1 --warmup 0 --no-cpu-baseline > $O/cfg3_b64_sampling.json 2> $O/cfg3.err; cut -c1-400 $O/cfg3_b64_sampling.json; echo ;;
     *) echo "unknown stage $st" ;;
   esac
 done

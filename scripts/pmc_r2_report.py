@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the per-kernel PMC means of scripts/gpu_pmc_r2.sh into the two round-2 summaries:
+"""Turn the per-kernel PMC means of scripts/archive/gpu_pmc_r2.sh (round 6: scripts/gpu_r6.sh, stage pmc) into the two round-2 summaries:
  r02_pmc_decode_traffic.json : HBM bytes per launch of the two decode launch classes (FETCH_SIZE doubled: gfx950 tallies the 128-byte
                                requests of a wide coalesced stream at 64 bytes, MI355X_MICROARCH.md, HBM; + WRITE_SIZE; units KiB)
  r02_pmc_dense_mfma.json     : matrix-core busy fraction of the dense-phase kernels = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) /

@@ -13,8 +13,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batches", default="1,8,16,64")
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--options", default="", help="engine options, e.g. gemm_xcd_swizzle=0")
+ap.add_argument("--phases", default="encode,prefill,detok", help="which phases run inside the loop (a kernel trace of ONE phase: --phases detok)")
 a = ap.parse_args()
 batches = [int(b) for b in a.batches.split(",")]
+phases = set(a.phases.split(","))
 cfg = MAConfig.full(dtype=DTYPE_BF16, max_batch=max(batches))
 eng = Engine(cfg)
 eng.load_weights(synthetic_items(cfg))
@@ -32,19 +34,25 @@ for B in batches:
     x = torch.cat([d * 0.9, d], dim=-1).half().cuda()
     ids = torch.randint(0, cfg.codebook_size, (B, cfg.n_max_faces * 9), generator=g).cuda()
     res = {}
+    if "encode" not in phases:
+        lat, prefix = eng.encode(x)
     for it in range(a.iters + 1):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        lat, prefix = eng.encode(x)
+        if "encode" in phases:
+            lat, prefix = eng.encode(x)
         ev[1].record()
-        toks, _ = eng.generate(prefix, max_new_tokens=1, suppress_eos=True)       # prefill + the first pick
+        if "prefill" in phases:
+            toks, _ = eng.generate(prefix, max_new_tokens=1, suppress_eos=True)       # prefill + the first pick
         ev[2].record()
-        coords = eng.detokenize(ids, lat)
+        if "detok" in phases:
+            coords = eng.detokenize(ids, lat)
         ev[3].record()
         torch.cuda.synchronize()
         if it:
-            for k, i in (("encode+prefix", 0), ("prefill", 1), ("detokenize", 2)):
-                res.setdefault(k, []).append(ev[i].elapsed_time(ev[i + 1]))
+            for k, i, ph in (("encode+prefix", 0, "encode"), ("prefill", 1, "prefill"), ("detokenize", 2, "detok")):
+                if ph in phases:
+                    res.setdefault(k, []).append(ev[i].elapsed_time(ev[i + 1]))
     line = f"[dense B={B:3d}]"
     tot_ms, tot_gf = 0.0, 0.0
     for k, v in res.items():

@@ -308,7 +308,7 @@ def test_sampling_with_injected_uniforms(tiny):
     u = np.random.default_rng(5).random((2, maxn)).astype(np.float32)
     toks, lengths = tiny.engine.generate(prefix.cuda(), sampling=True, uniforms=torch.from_numpy(u), suppress_eos=True)
     for b in range(2):
-        # bf16: the engine's logits sit within ~7e-3 of the bf16-policy oracle's (either dense-attention kernel, scripts/diag_r3d.py); on this
+        # bf16: the engine's logits sit within ~7e-3 of the bf16-policy oracle's (either dense-attention kernel, scripts/archive/diag_r3d.py); on this
         # 61-token vocabulary that moves a CDF boundary by up to a few percent -- same bound as the batched test above
         v = verify_sampled_stream(tiny.oracle, prefix[b:b + 1], toks[b].cpu(), u[b], tol=_tol(tiny, 1e-4, 5e-2), suppress_eos=True)
         assert v["hard"] == [], v

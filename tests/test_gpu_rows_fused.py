@@ -26,6 +26,8 @@ def eng(golden_dir):
     if not e.get_option("experimental"):
         pytest.skip("the rows-looped launches are not part of the product build (build and run with MA_EXPERIMENTAL=1)")
     load_weights_cached(e, cfg, init="diverse")
+    e.set_option("gemm_splitk", 0)                  # (the subject here is the decode form: keep the prefill's fc2 in ONE sum along K at every batch size -- at 8 .. ~38
+                                                    #  samples it is otherwise four partial sums, csrc/gemm256.hpp GemmSplitK, and a batch's rows differ from their batch-1 runs in the last bits)
     e.set_option("rows_fused", 1)                   # opt-in path (measured slower than the matrix-core chain; kept for its bit-identity property)
     if e.get_option("rows_fused") != 1:
         pytest.skip("the rows-looped launches are not available on this device (need 256 CUs with 130 KB of LDS each)")
