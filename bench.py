@@ -441,7 +441,8 @@ def main():
             eng_b.close()
             torch.cuda.empty_cache()
             # the parity ("exact") mode's throughput: the same mesh with fp32 weights, fp32 KV cache and no activation rounding -- the mode the
-            # token-identity / 1e-5 gates of tests/ run in (five launches per layer: the fused launches are bf16-only)
+            # token-identity / 1e-5 gates of tests/ run in (round 6: on the same two fused launches per layer as the 16-bit policies, with the
+            # five-launch chain's fp32 summation order kept bit for bit)
             cfg_x = MAConfig.full(dtype=DTYPE_F32, n_max_faces=args.faces, max_batch=1)
             eng_x = Engine(cfg_x, local_rank)
             eng_x.load_weights(sd.items())
@@ -453,6 +454,8 @@ def main():
             t_x = time.perf_counter() - t1
             assert tuple(ox["tokens"].shape) == (1, cfg_x.max_new_tokens)
             fp32_exact = {"face_tokens_per_s": round(cfg_x.max_new_tokens / t_x, 1), "sec_per_mesh": round(t_x, 3), "meshes_timed": 1,
+                          "fused_qkv_attn": int(eng_x.get_option("fuse_qkv_attn")), "fused_oproj_fc1": int(eng_x.get_option("fuse_oproj_fc1")),
+                          "chain_fallbacks": int(eng_x.get_option("chain_fallbacks")),
                           "note": "MA_DTYPE_F32 policy, same cloud and weights, one warm mesh; streams 2x the bytes of the bf16 policy"}
             eng_x.close()
             # the reference's own arithmetic class (fp16 autocast, main.py:114-118,149): the same mesh under MA_DTYPE_F16 -- same kernels, IEEE half

@@ -193,7 +193,7 @@ struct ma_engine {
     bool rf_ok = false;              // its second launch (130 KB of LDS) can be resident on every CU of this device
     u64* d_part_gran = nullptr;      // [max_batch][heads][16][66] granules: its in-launch split-KV partial exchange
     int opt_qkv_xcd_local = 1;       // fused q/k/v + attention launch: the 16 blocks of a head on one XCD (qkv_attn.hpp qkv_block_role)
-    int opt_fuse_qkv_attn = 1;       // launch chain, bf16, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
+    int opt_fuse_qkv_attn = 1;       // launch chain, any policy, hidden 1024: q/k/v projection and decode attention in ONE launch (qkv_attn.hpp)
     u64* d_qkv_gran = nullptr;       // its exchange buffer: [max_batch][3 hidden] granules
     int opt_fuse_oproj_fc1 = 1;      // ... and out_proj (+ partial merge) + LayerNorm + fc1 in ONE launch (oproj_fc1.hpp)
     u64* d_y1_gran = nullptr;        // [max_batch][hidden] granules
@@ -695,10 +695,10 @@ void enqueue_layers_mfma(ma_engine* e, hipStream_t s, const float* x_embed, int 
 // such a caller does not advance) take the five-launch chain.
 bool chain_fits(ma_engine* e, int B, int len_override) { return e->chain_resident && len_override < 0 && e->resident_blocks * 4 >= 256L * B * 5; }
 bool fuse_oproj_fc1(ma_engine* e, int B = 1, int len_override = -1) {
-    return e->opt_fuse_oproj_fc1 && chain_fits(e, B, len_override) && e->bf16 && e->cfg.hidden == 1024 && e->cfg.ffn == 4096 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
+    return e->opt_fuse_oproj_fc1 && chain_fits(e, B, len_override) && e->cfg.hidden == 1024 && e->cfg.ffn == 4096 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
 }
 bool fuse_qkv_attn(ma_engine* e, int B = 1, int len_override = -1) {
-    return e->opt_fuse_qkv_attn && chain_fits(e, B, len_override) && e->bf16 && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
+    return e->opt_fuse_qkv_attn && chain_fits(e, B, len_override) && e->cfg.hidden == 1024 && e->cfg.heads * 64 == e->cfg.hidden && e->cfg.layers <= 30;
 }
 
 // one OPT layer of one decode step.  `x_in` = this layer's input (row stride H) before its (optional) LayerNorm prologue.
@@ -744,7 +744,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         QkvAttnArgs a = make_qkv_attn_args(e, l, x_in, ln_g, ln_b, len_override, rw);
         a.trace = tm.trace_slot(2, ATTN_NCHUNK * c.heads);
         if (tm.on(1)) {
-            hipError_t r = H16_CALL(e->hdt, HT, launch_qkv_attn<HT>(a, c.heads, B, s));
+            hipError_t r = e->bf16 ? H16_CALL(e->hdt, HT, launch_qkv_attn<HT>(a, c.heads, B, s)) : launch_qkv_attn<float>(a, c.heads, B, s);
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("qkv_attn launch failed: ") + hipGetErrorString(r));
         }
     } else {
@@ -772,7 +772,7 @@ void enqueue_layer(ma_engine* e, hipStream_t s, int l, const float* x_in, const 
         OprojFc1Args a = make_oproj_fc1_args(e, l, resid, rw, with_fc2);
         a.trace = tm.trace_slot(3, H / 4);
         if (tm.on(0)) {
-            hipError_t r = H16_CALL(e->hdt, HT, launch_oproj_fc1<HT>(a, H, c.ffn, B, s));
+            hipError_t r = e->bf16 ? H16_CALL(e->hdt, HT, launch_oproj_fc1<HT>(a, H, c.ffn, B, s)) : launch_oproj_fc1<float>(a, H, c.ffn, B, s);
             if (r != hipSuccess) throw MaError(MA_ERR_HIP, std::string("oproj_fc1 launch failed: ") + hipGetErrorString(r));
         }
     } else {
@@ -1399,13 +1399,19 @@ void build_engine(ma_engine* e) {
             // API can report one block per CU too many (MI355X guide, correctness boundaries), so one block per CU is taken off and a
             // quarter is kept as margin; a partitioned device (CPX: 32 CUs) falls back to the five-launch chain.
             int occ_a = 0, occ_b = 0, occ_c = 1 << 20;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, qkv_attn_kernel<PRO_LN>, 256, 0) != hipSuccess ||
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, oproj_fc1_kernel<4, true>, 256, 0) != hipSuccess) { (void)hipGetLastError(); occ_a = occ_b = 0; }
+            // (the fp32 policy's instantiations hold twice the weight registers: asked about separately)
+            const hipError_t qa = e->bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, qkv_attn_kernel<PRO_LN>, 256, 0)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_a, qkv_attn_kernel<PRO_LN, float>, 256, 0);
+            const hipError_t qb = e->bf16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, oproj_fc1_kernel<4, true>, 256, 0)
+                                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, oproj_fc1_kernel<4, true, float>, 256, 0);
+            if (qa != hipSuccess || qb != hipSuccess) { (void)hipGetLastError(); occ_a = occ_b = 0; }
 #ifdef MA_EXPERIMENTAL
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, layer_fused_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); occ_c = 0; }
 #endif
             const int occ_min = std::min(std::min(occ_a, occ_b), occ_c);
-            const int usable = occ_min > 1 ? occ_min - 1 : occ_min;              // blocks per CU counted on
+            // (a register-bound occupancy of two -- the fp32 instantiations at 171-210 VGPRs -- is exact: the over-report concerns the SGPR-limited
+            // high-occupancy cases; 512 slots for the 256 blocks of batch 1 is the quarter of margin and more)
+            const int usable = occ_min > 2 ? occ_min - 1 : occ_min;              // blocks per CU counted on
             e->resident_blocks = (long)e->n_cus * usable;
             e->chain_resident = e->resident_blocks * 4 >= 256L * 5;
             // the two-launch 8-row layer: 256 blocks of 8 waves at ~190-236 registers = one block per CU -- a register / wave-slot bound, where the

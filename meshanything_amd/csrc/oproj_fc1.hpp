@@ -1,4 +1,4 @@
-// Second half of a decoder layer in one launch, batch-1 launch chain (bf16 policy, hidden 1024, ffn 4096): merge of the split-KV
+// Second half of a decoder layer in one launch, batch-1 launch chain (any policy: templated on the storage format; hidden 1024, ffn 4096): merge of the split-KV
 // partials + out_proj + residual, LayerNorm 1, fc1 + ReLU and (template FC2, the default) fc2 + residual.
 //
 // Replaces three launches of the five-launch chain ([3p] OPTDecoderLayer: out_proj + residual, self_attn_layer_norm, fc1 + ReLU, fc2 +
@@ -24,6 +24,24 @@
 #include "state.hpp"
 
 namespace ma {
+
+// pieces of 16 bytes per lane and 1024 elements of a weight row, and how gemv_kernel sums them, per storage format: the 16-bit policies run
+// whole rows in one wave ({1, 2, *} and {1, 8, 1} shapes: ONE sum per row); the fp32 policy (round 6) splits K between waves ({2, 2, *} at
+// K = 1024, {4, 4, 1} at K = 4096) and adds the per-wave sums in ascending order -- here one wave keeps the SAME partial sums apart.  In the
+// fp32 policy the structs' bf16_t pointers are plain addresses of fp32 storage.
+template <typename HT> struct OfStore { typedef HT T; static constexpr int VEC = 8, NP = 2, PARTS1 = 1, PARTS2 = 1; };
+template <> struct OfStore<float> { typedef float T; static constexpr int VEC = 4, NP = 4, PARTS1 = 2, PARTS2 = 4; };
+// sum of PARTS per-wave partials the way gemv_kernel's finishing lane adds them (v = 0; v += red[0]; v += red[1]; ...)
+template <int PARTS>
+__device__ __forceinline__ float of_sum_parts(const float (&acc)[PARTS]) {
+    if constexpr (PARTS == 1) return wave_sum(acc[0]);
+    else {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < PARTS; ++k) v += wave_sum(acc[k]);
+        return v;
+    }
+}
 
 struct OprojFc1Args {
     const bf16_t* Wo; const float* bo;                   // [hidden][hidden], [hidden]
@@ -51,7 +69,12 @@ constexpr unsigned OF_ERR_GATHER = 32;
 template <int NSW, bool FC2, bool NEXT, typename HT, typename Hook>
 __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, const int brow, float* ynext, u64* gran3, Hook&& after_ffn_publish) {
     constexpr int KC = 1024, KF = 4096;
-    __shared__ __attribute__((aligned(16))) float ffl[FC2 ? KF : 4];      // relu(fc1), rounded to bf16 (fc2's input)
+    typedef typename OfStore<HT>::T ST;
+    constexpr int VEC = OfStore<HT>::VEC, NP = OfStore<HT>::NP, NP2 = 4 * NP, P1 = OfStore<HT>::PARTS1, P2 = OfStore<HT>::PARTS2;
+    const ST* const Wo = reinterpret_cast<const ST*>(a.Wo);
+    const ST* const W1 = reinterpret_cast<const ST*>(a.W1);
+    const ST* const W2 = reinterpret_cast<const ST*>(a.W2);
+    __shared__ __attribute__((aligned(16))) float ffl[FC2 ? KF : 4];      // relu(fc1), rounded to the weights' format (fc2's input)
     __shared__ float h1l[FC2 ? 4 : 1];                                    // LN1(y1)[4b + w]: fc2's residual
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ __attribute__((aligned(16))) float yraw[KC];
@@ -73,18 +96,18 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     // slower in both formats (profiles/r04_ab_load_pinning.txt).
     if constexpr (__is_same(HT, f16_t)) __builtin_amdgcn_sched_barrier(0);
     const int orow = 4 * b + w;                          // out_proj row of this wave
-    u32x4 wo[2];
+    u32x4 wo[NP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) wo[i] = ld_stream16(a.Wo + (size_t)orow * KC + (i * 64 + lane) * 8);
+    for (int i = 0; i < NP; ++i) wo[i] = ld_stream16(Wo + (size_t)orow * KC + (i * 64 + lane) * VEC);
     const float e_bo = a.bo[orow], e_res = a.res[(size_t)brow * a.res_stride + orow];
-    u32x4 w1[4][2];
+    u32x4 w1[4][NP];
     float e_b1[4];
     f32x4 gv[1], bv[1];
     auto load_fc1 = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) w1[j][i] = ld_stream16(a.W1 + (size_t)(16 * b + 4 * w + j) * KC + (i * 64 + lane) * 8);
+            for (int i = 0; i < NP; ++i) w1[j][i] = ld_stream16(W1 + (size_t)(16 * b + 4 * w + j) * KC + (i * 64 + lane) * VEC);
 #pragma unroll
         for (int j = 0; j < 4; ++j) e_b1[j] = a.b1[16 * b + 4 * w + j];
         gv[0] = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
@@ -102,21 +125,23 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     __syncthreads();
     float y1;
     {
-        float acc = 0.f;
+        float acc[P1];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k0 = (i * 64 + lane) * 8;
-            float xs[8], wf[8];
+        for (int k = 0; k < P1; ++k) acc[k] = 0.f;
 #pragma unroll
-            for (int v = 0; v < 8; v += 4) {
+        for (int i = 0; i < NP; ++i) {
+            const int k0 = (i * 64 + lane) * VEC;
+            float xs[VEC], wf[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v += 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
                 xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
             }
-            unpack16<HT>(wo[i], wf);
+            unpack16<ST>(wo[i], wf);
 #pragma unroll
-            for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
+            for (int v = 0; v < VEC; ++v) acc[i * P1 / NP] = fmaf(wf[v], xs[v], acc[i * P1 / NP]);
         }
-        float v = wave_sum(acc);
+        float v = of_sum_parts<P1>(acc);
         v += e_bo;
         v += e_res;
         y1 = v;
@@ -126,11 +151,11 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     // ---- (3) all-gather of y1: one granule per wave out, all 1024 in --------------------------------------------------
     u64* gran = a.gran + (size_t)brow * KC;
     if (lane == 0) ps_publish(gran, orow, epoch, __float_as_uint(y1));
-    u32x4 w2[FC2 ? 8 : 1];
+    u32x4 w2[FC2 ? NP2 : 1];
     float e_b2 = 0.f;
     if constexpr (FC2) {                                 // fc2's row: not needed before the second exchange, requested under the first
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w2[i] = ld_stream16(a.W2 + (size_t)orow * KF + (i * 64 + lane) * 8);
+        for (int i = 0; i < NP2; ++i) w2[i] = ld_stream16(W2 + (size_t)orow * KF + (i * 64 + lane) * VEC);
         e_b2 = a.b2[orow];
         asm volatile("" ::: "memory");
     }
@@ -185,28 +210,32 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
     }
     __syncthreads();
-    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc4[4][P1];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k0 = (i * 64 + lane) * 8;
-        float xs[8];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int v = 0; v < 8; v += 4) {
+        for (int k = 0; k < P1; ++k) acc4[j][k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int k0 = (i * 64 + lane) * VEC;
+        float xs[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
             xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float wf[8];
-            unpack16<HT>(w1[j][i], wf);
+            float wf[VEC];
+            unpack16<ST>(w1[j][i], wf);
 #pragma unroll
-            for (int v = 0; v < 8; ++v) acc4[j] = fmaf(wf[v], xs[v], acc4[j]);
+            for (int v = 0; v < VEC; ++v) acc4[j][i * P1 / NP] = fmaf(wf[v], xs[v], acc4[j][i * P1 / NP]);
         }
     }
     float outv = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float v = wave_sum(acc4[j]);
+        float v = of_sum_parts<P1>(acc4[j]);
         v += e_b1[j];
         v = fmaxf(v, 0.0f);
         if (lane == j) outv = v;
@@ -217,11 +246,46 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     } else {
         // ---- (5) all-gather of relu(fc1).  fc2 consumes it rounded to bf16, so a granule carries TWO values (bf16 pair + epoch): 2 granules
         //      per wave out, 2048 in all, wave w sweeps granules [512 w, 512 w + 512) -- half the polling of one value per granule ------------
+        //      fp32 policy: the value is consumed unrounded, one fp32 per granule (4096 granules, 1024 per wave in two passes of eight loads)
         u64* g2 = a.gran2 + (size_t)brow * KF;
-        {
+        if constexpr (sizeof(ST) == 4) {
+            if (lane < 4) ps_publish(g2, 16 * b + 4 * w + lane, epoch, __float_as_uint(outv));
+            after_ffn_publish();
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                const gu64* g64 = (const gu64*)g2 + w * 1024 + half * 512;
+                float* fr = ffl + w * 1024 + half * 512;
+                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0, pend = 0xffu;
+                for (;;) {
+                    u64 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[k] = (u64)epoch << 32;
+                        if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if ((pend >> k) & 1u) {
+                            const bool ok = (unsigned)(v[k] >> 32) == epoch;
+                            if (ok) fr[k * 64 + lane] = __uint_as_float((unsigned)v[k]);
+                            if (__all(ok)) pend &= ~(1u << k);
+                        }
+                    }
+                    if (!pend) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (xchg_expired(spins, t0, a.err)) {
+                        if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) fr[k * 64 + lane] = 0.f;
+                        break;
+                    }
+                }
+                if (lane == 0) xchg_note_slow(a.err, spins, t0);
+            }
+        } else {
             const float nb = __shfl_down(outv, 1, 64);
             if (lane == 0 || lane == 2) ps_publish(g2, 8 * b + 2 * w + (lane >> 1), epoch, H16<HT>::pack2(outv, nb));
-        }
         after_ffn_publish();                             // the caller's next requests ride under this exchange
         {
             const gu64* g64 = (const gu64*)g2 + w * 512;
@@ -254,24 +318,27 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             }
             if (lane == 0) xchg_note_slow(a.err, spins, t0);
         }
+        }
         __syncthreads();
         if (a.trace && tid == 0) a.trace[b * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-        // ---- (6) fc2: gemv_kernel<bf16_t, 1, 8, 1, PRO_PLAIN>, row 4b + w ---------------------------------------------------------------
-        float acc = 0.f;
+        // ---- (6) fc2: gemv_kernel<bf16_t, 1, 8, 1, PRO_PLAIN> (fp32: <float, 4, 4, 1, PRO_PLAIN>), row 4b + w -------------------------------
+        float acc[P2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k0 = (i * 64 + lane) * 8;
-            float xs[8], wf[8];
+        for (int k = 0; k < P2; ++k) acc[k] = 0.f;
 #pragma unroll
-            for (int v = 0; v < 8; v += 4) {
+        for (int i = 0; i < NP2; ++i) {
+            const int k0 = (i * 64 + lane) * VEC;
+            float xs[VEC], wf[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v += 4) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(&ffl[k0 + v]);
                 xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
             }
-            unpack16<HT>(w2[i], wf);
+            unpack16<ST>(w2[i], wf);
 #pragma unroll
-            for (int v = 0; v < 8; ++v) acc = fmaf(wf[v], xs[v], acc);
+            for (int v = 0; v < VEC; ++v) acc[i * P2 / NP2] = fmaf(wf[v], xs[v], acc[i * P2 / NP2]);
         }
-        float v = wave_sum(acc);
+        float v = of_sum_parts<P2>(acc);
         v += e_b2;
         v += h1l[w];
         if constexpr (!NEXT) {

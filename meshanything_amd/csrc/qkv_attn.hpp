@@ -1,4 +1,4 @@
-// Fused q/k/v projection + split-KV decode attention of one layer, batch-1 launch chain (bf16 policy, hidden = 1024).
+// Fused q/k/v projection + split-KV decode attention of one layer, batch-1 launch chain (any policy: templated on the storage format; hidden = 1024).
 //
 // Replaces two launches of the chain -- the fused-QKV GEMV (gemv.hpp, EPI_QKV; [3p] OPTAttention q/k/v projections reached from
 // shape_opt.py:403-410) and the split-KV attention (attn_decode.hpp; [3p] OptFlashAttention2 + the per-step torch.cat) -- by one:
@@ -42,9 +42,16 @@ constexpr unsigned QA_ERR_GATHER = 16;
 
 // the operands of a block that do not depend on the input vector: its 12 weight rows (4 waves x q, k, v), their biases, the LayerNorm
 // parameters.  A caller that runs other work first (layer_fused.hpp) requests them early and hands them over.
-struct QkvOperands { u32x4 wv[3][2]; float bq[3]; f32x4 gv, bv; };
-template <int PRO>
-__device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const int c, const int h, QkvOperands& op) {
+// NP = 16-byte pieces per lane and weight row: 2 in the 16-bit policies (8 elements each), 4 in the fp32 policy (4 elements each; round 6: the fp32
+// policy on the fused chain -- the struct's bf16_t pointers are then plain addresses of fp32 storage, reinterpreted here)
+template <typename HT> struct QkvStore { typedef HT T; typedef uint16_t Word; static constexpr int VEC = 8, NP = 2; };
+template <> struct QkvStore<float> { typedef float T; typedef float Word; static constexpr int VEC = 4, NP = 4; };
+template <int NP> struct QkvOperandsT { u32x4 wv[3][NP]; float bq[3]; f32x4 gv, bv; };
+typedef QkvOperandsT<2> QkvOperands;
+template <int PRO, typename HT = bf16_t>
+__device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const int c, const int h, QkvOperandsT<QkvStore<HT>::NP>& op) {
+    typedef typename QkvStore<HT>::T ST;
+    constexpr int VEC = QkvStore<HT>::VEC, NP = QkvStore<HT>::NP;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if constexpr (PRO == PRO_LN) {
         op.gv = *reinterpret_cast<const f32x4*>(a.ln_g + tid * 4);
@@ -53,9 +60,9 @@ __device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const in
     const int row = 64 * h + 4 * c + w;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const bf16_t* wr = a.W + (size_t)(p * a.hidden + row) * 1024;
+        const ST* wr = reinterpret_cast<const ST*>(a.W) + (size_t)(p * a.hidden + row) * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) op.wv[p][i] = ld_stream16(wr + (i * 64 + lane) * 8);
+        for (int i = 0; i < NP; ++i) op.wv[p][i] = ld_stream16(wr + (i * 64 + lane) * VEC);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) op.bq[p] = a.bias[p * a.hidden + row];
@@ -65,14 +72,17 @@ __device__ __forceinline__ void qkv_load_operands(const QkvAttnArgs& a, const in
 // requested by the caller.
 // HT: the 16-bit format of the weights and the cache (bf16_t | f16_t, common.hpp H16)
 template <int PRO, bool XLDS, typename HT = bf16_t>
-__device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const int h, const int nheads, const int brow, const float* xlds, QkvOperands& op) {
-    typedef AttnGeom<HT> G;
+__device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const int h, const int nheads, const int brow, const float* xlds, QkvOperandsT<QkvStore<HT>::NP>& op) {
+    typedef typename QkvStore<HT>::T ST;                             // storage element of the weights and the cache
+    constexpr int VEC = QkvStore<HT>::VEC, NP = QkvStore<HT>::NP;
+    typedef AttnGeom<ST> G;
     constexpr int KC = 1024;
     __shared__ __attribute__((aligned(16))) float xl[KC];
     __shared__ float red[8];
-    __shared__ __attribute__((aligned(16))) float qg[64];            // q_h, already rounded to bf16 (one conversion per lane, by the sweeping wave)
-    __shared__ __attribute__((aligned(16))) bf16_t kvg[128];        // newest position's k_h | v_h as bf16 (what the cache holds)
-    __shared__ AttnMergeLds<HT> S;
+    __shared__ __attribute__((aligned(16))) float qg[64];            // q_h, already rounded to the cache format (one conversion per lane, by the sweeping wave)
+    typedef typename QkvStore<HT>::Word KW;                          // the cache's element as a plain word (uint16_t | float)
+    __shared__ __attribute__((aligned(16))) KW kvg[128];            // newest position's k_h | v_h in the cache's format (what the cache holds)
+    __shared__ AttnMergeLds<ST> S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Hd = a.hidden;
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -91,12 +101,12 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     if constexpr (XLDS) xv[0] = *reinterpret_cast<const f32x4*>(xlds + tid * 4);
     else xv[0] = *reinterpret_cast<const f32x4*>(x + tid * 4);
     if constexpr (PRO == PRO_LN) x0 = XLDS ? xlds[0] : x[0];
-    if constexpr (!XLDS) qkv_load_operands<PRO>(a, c, h, op);
+    if constexpr (!XLDS) qkv_load_operands<PRO, HT>(a, c, h, op);
     const int row = 64 * h + 4 * c + w;                  // this wave's row inside each of the q, k, v blocks of the fused matrix
     f32x4 gv[1] = {op.gv}, bv[1] = {op.bv};
     const int slot = lane / G::LPP, dsub = lane % G::LPP, woff = w * 32;
-    const bf16_t* kh = a.kcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
-    const bf16_t* vh = a.vcache + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
+    const ST* kh = reinterpret_cast<const ST*>(a.kcache) + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
+    const ST* vh = reinterpret_cast<const ST*>(a.vcache) + (size_t)brow * a.kv_row_stride + (size_t)h * a.max_seq * 64 + dsub * G::EPL;
     u32x4 kA[G::U], vA[G::U], kB[G::U], vB[G::U];
     auto issue = [&](int r, u32x4 (&kr)[G::U], u32x4 (&vr)[G::U]) {
         const int base = start + (r << 7) + woff + slot;
@@ -116,27 +126,35 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
         *reinterpret_cast<f32x4*>(&xl[tid * 4]) = r;
     }
     __syncthreads();
-    float acc[3] = {0.f, 0.f, 0.f};
+    // fp32: gemv_kernel<float, 2, 2, *> splits K between two waves (pieces 0, 1 | 2, 3) and adds the halves in LDS: the same two half-sums here, in one wave
+    constexpr int NH = NP / 2;                                       // halves of K that are summed apart (1: the 16-bit policies' one sum)
+    float acc[NH][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int k0 = (i * 64 + lane) * 8;
-        float xs[8];
+    for (int hf = 0; hf < NH; ++hf) { acc[hf][0] = 0.f; acc[hf][1] = 0.f; acc[hf][2] = 0.f; }
 #pragma unroll
-        for (int v = 0; v < 8; v += 4) {
+    for (int i = 0; i < NP; ++i) {
+        const int k0 = (i * 64 + lane) * VEC;
+        float xs[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(&xl[k0 + v]);
             xs[v] = t.x; xs[v + 1] = t.y; xs[v + 2] = t.z; xs[v + 3] = t.w;
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            float wf[8];
-            unpack16<HT>(op.wv[p][i], wf);
+            float wf[VEC];
+            unpack16<ST>(op.wv[p][i], wf);
 #pragma unroll
-            for (int v = 0; v < 8; ++v) acc[p] = fmaf(wf[v], xs[v], acc[p]);
+            for (int v = 0; v < VEC; ++v) acc[i / 2 % NH][p] = fmaf(wf[v], xs[v], acc[i / 2 % NH][p]);
         }
     }
     float out3[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) { float v = wave_sum(acc[p]); v += op.bq[p]; out3[p] = v; }
+    for (int p = 0; p < 3; ++p) {
+        float v = wave_sum(acc[0][p]);
+        if constexpr (NH == 2) { float t = 0.f; t += v; t += wave_sum(acc[1][p]); v = t; }      // (v = 0 + half 0 + half 1: gemv_kernel's order)
+        v += op.bq[p]; out3[p] = v;
+    }
     if (a.trace && tid == 0) a.trace[(h * ATTN_NCHUNK + c) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- (3) exchange inside the head: publish 3 values per wave, wave 0 sweeps what this block needs -----------------------------
@@ -163,8 +181,8 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
             }
             if (__all(ok)) {
                 qg[lane] = H16<HT>::round(__uint_as_float((unsigned)v[0]));
-                kvg[lane] = H16<HT>::bits(__uint_as_float((unsigned)v[1]));
-                kvg[64 + lane] = H16<HT>::bits(__uint_as_float((unsigned)v[2]));
+                if constexpr (sizeof(ST) == 4) { kvg[lane] = __uint_as_float((unsigned)v[1]); kvg[64 + lane] = __uint_as_float((unsigned)v[2]); }
+                else { kvg[lane] = H16<HT>::bits(__uint_as_float((unsigned)v[1])); kvg[64 + lane] = H16<HT>::bits(__uint_as_float((unsigned)v[2])); }
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -176,9 +194,10 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
         }
         if (lane == 0) xchg_note_slow(a.err, spins, t0);
         if (c == c_last && lane < 32) {                  // the newest position joins the cache (read by later steps' launches)
-            const u32x2 pk = *reinterpret_cast<const u32x2*>(kvg + (lane >> 4) * 64 + (lane & 15) * 4);
-            bf16_t* plane = (lane >> 4) ? a.vcache : a.kcache;
-            *reinterpret_cast<u32x2*>(plane + (size_t)brow * a.kv_row_stride + ((size_t)h * a.max_seq + pos) * 64 + (lane & 15) * 4) = pk;
+            KW* plane = reinterpret_cast<KW*>((lane >> 4) ? a.vcache : a.kcache) + (size_t)brow * a.kv_row_stride + ((size_t)h * a.max_seq + pos) * 64 + (lane & 15) * 4;
+            const KW* src = kvg + (lane >> 4) * 64 + (lane & 15) * 4;      // four elements per lane
+            if constexpr (sizeof(ST) == 4) *reinterpret_cast<f32x4*>(plane) = *reinterpret_cast<const f32x4*>(src);
+            else *reinterpret_cast<u32x2*>(plane) = *reinterpret_cast<const u32x2*>(src);
         }
     }
     __syncthreads();
@@ -186,22 +205,23 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
 
     // ---- (4) attention over chunk c (attn_decode.hpp, the launch chain's arithmetic; the newest position from the granules) ----------
     float qv[G::EPL];
-    {
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qg + dsub * G::EPL), q1 = *reinterpret_cast<const f32x4*>(qg + dsub * G::EPL + 4);
-        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+#pragma unroll
+    for (int e = 0; e < G::EPL; e += 4) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qg + dsub * G::EPL + e);
+        qv[e] = q0.x; qv[e + 1] = q0.y; qv[e + 2] = q0.z; qv[e + 3] = q0.w;
     }
     const u32x4 ok4 = *reinterpret_cast<const u32x4*>(kvg + dsub * G::EPL), ov4 = *reinterpret_cast<const u32x4*>(kvg + 64 + dsub * G::EPL);
     const int ovr = c == c_last ? pos : -1;
-    AttnSlotState<HT> ss;
+    AttnSlotState<ST> ss;
     ss.m = -1e30f; ss.l = 0.f;
 #pragma unroll
     for (int e = 0; e < G::EPL; ++e) ss.o[e] = 0.f;
     for (int r = 0; r < nround; r += 2) {
         if (r + 1 < nround) issue(r + 1, kB, vB);
-        attn_round_reduce<HT, true>(ss, qv, kA, vA, start + (r << 7) + woff + slot, end, ovr, ok4, ov4);
+        attn_round_reduce<ST, true>(ss, qv, kA, vA, start + (r << 7) + woff + slot, end, ovr, ok4, ov4);
         if (r + 1 < nround) {
             if (r + 2 < nround) issue(r + 2, kA, vA);
-            attn_round_reduce<HT, true>(ss, qv, kB, vB, start + ((r + 1) << 7) + woff + slot, end, ovr, ok4, ov4);
+            attn_round_reduce<ST, true>(ss, qv, kB, vB, start + ((r + 1) << 7) + woff + slot, end, ovr, ok4, ov4);
         }
     }
     const int gs = w * G::PPW + slot;
@@ -211,14 +231,14 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     __syncthreads();
     {
         float M, L, O;
-        attn_fold_quarter<HT>(S, w, lane, M, L, O);
+        attn_fold_quarter<ST>(S, w, lane, M, L, O);
         if (lane == 0) { S.qm[w] = M; S.ql[w] = L; }
         S.qo[w][lane] = O;
     }
     __syncthreads();
     if (w == 0) {
         float M, L, O;
-        attn_fold_block<HT>(S, lane, M, L, O);
+        attn_fold_block<ST>(S, lane, M, L, O);
         float* ws = a.ws + (size_t)brow * attn_workspace_floats(nheads);
         float* ml = ws + ((size_t)h * ATTN_NCHUNK + c) * 2;
         float* op = ws + (size_t)nheads * ATTN_NCHUNK * 2 + ((size_t)h * ATTN_NCHUNK + c) * 64;
@@ -243,7 +263,7 @@ __device__ __forceinline__ void qkv_block_role(const QkvAttnArgs& a, int& c, int
 
 template <int PRO, typename HT = bf16_t>
 __global__ __launch_bounds__(256) void qkv_attn_kernel(QkvAttnArgs a) {
-    QkvOperands op;
+    QkvOperandsT<QkvStore<HT>::NP> op;
     int c, h;
     qkv_block_role(a, c, h);
     qkv_attn_body<PRO, false, HT>(a, c, h, gridDim.y, blockIdx.z, nullptr, op);

@@ -17,6 +17,11 @@ for st in $STAGES; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt ;;
     exp)
       MA_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_persist.py tests/test_gpu_rows_fused.py tests/test_gpu_rows_attn.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids > $O/suite_experimental.txt; tail -3 $O/suite_experimental.txt ;;
+    fp32)
+      # the fp32 ("exact") policy on the fused batch-1 chain: bitwise against the five-launch chain, the long-context / reference-anchor gates, one timed mesh each way
+      timeout 900 python -m pytest tests/test_gpu_persist.py -x -q -p no:cacheprovider -s -k "fp32 and (fused or fc2)" 2>&1 | grep -v amdgpu.ids > $O/fp32_fused_bitwise.txt; grep -E "A/B|passed|failed|Error|assert" $O/fp32_fused_bitwise.txt | cut -c1-300 | tail -20
+      timeout 900 python -m pytest tests/test_gpu_long_context.py tests/test_gpu_reference_anchor.py -x -q -p no:cacheprovider -k "fp32" 2>&1 | grep -v amdgpu.ids > $O/fp32_gates.txt; tail -4 $O/fp32_gates.txt
+      timeout 600 python scripts/time_fp32_policy.py 2>&1 | grep -v amdgpu.ids > $O/fp32_policy_mesh.txt; cat $O/fp32_policy_mesh.txt ;;
     dense)
       timeout 600 python scripts/prof_dense.py --batches ${BATCHES:-16,64} 2>&1 | grep -v amdgpu.ids > $O/dense.txt; cat $O/dense.txt
       cd /tmp; rm -rf /tmp/prof_d

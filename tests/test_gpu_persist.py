@@ -13,11 +13,11 @@ from conftest import cached_state_dict, load_weights_cached
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["bf16", "fp16"])
+@pytest.fixture(scope="module", params=["bf16", "fp16", "fp32"])       # fp32: the "exact" policy runs the same two fused launches since round 6
 def eng(request, golden_dir):
     from meshanything_amd.engine import Engine
-    from meshanything_amd.config import DTYPE_F16
-    cfg = MAConfig.full(dtype=DTYPE_BF16 if request.param == "bf16" else DTYPE_F16, max_batch=2)
+    from meshanything_amd.config import DTYPE_F16, DTYPE_F32
+    cfg = MAConfig.full(dtype={"bf16": DTYPE_BF16, "fp16": DTYPE_F16, "fp32": DTYPE_F32}[request.param], max_batch=2)
     e = Engine(cfg)
     load_weights_cached(e, cfg, init="diverse")           # a greedy stream that depends on its own tokens (checkpoint.py)
     d = dict(np.load(os.path.join(golden_dir, "dataset.npz")))
