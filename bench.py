@@ -33,7 +33,7 @@ from meshanything_amd.checkpoint import synthetic_state_dict          # noqa: E4
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 # health counters of the fused decode launches (ma_engine_get_option): generations that fell back to the launch chain, sweeps that gave up, the error word of
 # the last fall-back, scalar sweeps a vector look had to finish (rows_attn.hpp), long-lived blocks
-HEALTH_KEYS = ("chain_resident", "chain_fallbacks", "xchg_timeouts", "xchg_last_code", "scalar_sweep_rescues", "slow_blocks", "slow_block_max_us")
+HEALTH_KEYS = ("chain_resident", "chain_fallbacks", "xchg_timeouts", "xchg_last_code", "scalar_sweep_rescues", "slow_blocks", "slow_block_max_us", "xchg_descheduled")
 
 
 def synth_cloud(seed: int, n: int) -> np.ndarray:

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_final_kernel(const float*
                 return;
             }
             unsigned long long vo = 0, vm = (unsigned long long)epoch << 32;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            u64 t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0;
             for (;;) {
                 vo = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

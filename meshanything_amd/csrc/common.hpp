@@ -284,9 +284,21 @@ __device__ __forceinline__ void ps_publish(u64* gran, int idx, unsigned epoch, u
 // Bounded sweep: true when the polling wave must give up -- its own deadline passed, or some block of this generation already raised
 // the engine's error word (then every later sweep gives up after at most 64 polls instead of burning its own 20 ms: a launch whose
 // blocks are not all resident costs one deadline, not one per launch).  Checked every 64th poll only: nothing on the fast path.
-__device__ __forceinline__ bool xchg_expired(unsigned& spins, u64 t0, const unsigned* err) {
+// The deadline is 20 ms OF POLLING, not of the wall clock alone (round 6): a wave that the clock says has been sweeping for 20 ms but that has made
+// fewer than PS_MIN_POLLS polls (a healthy sweep ends within ~100; a starved one makes 1024 in 2 - 5 ms) was not running in between -- the driver
+// took the process's queues off the device and put them back (waves saved and restored together, so co-residency holds; seen as 20 - 30 ms holes
+// in profiled runs since round 3, and as a lone "time-out" of ~50 waves -- the ones inside a sweep at that instant -- in a generation that had
+// every block resident).  Such a sweep restarts its clock, counts itself in err[8] ("xchg_descheduled") and goes on; it can do so only while
+// its poll count is below the minimum, so a sweep that really waits for a block that is not there still ends: after 1024 polls + 20 ms at most.
+constexpr unsigned PS_MIN_POLLS = 1024u;
+__device__ __forceinline__ bool xchg_expired(unsigned& spins, u64& t0, unsigned* err) {
     if ((++spins & 63u) != 0) return false;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > PS_TIMEOUT_TICKS) return true;
+    const u64 now = __builtin_amdgcn_s_memrealtime();
+    if (now - t0 > PS_TIMEOUT_TICKS) {
+        if (spins >= PS_MIN_POLLS) return true;
+        t0 = now;
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) __hip_atomic_fetch_add(err + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 

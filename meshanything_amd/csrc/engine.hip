@@ -831,7 +831,7 @@ void enqueue_layer_rows_fused(ma_engine* e, hipStream_t s, int l, const float* x
     }
 }
 
-bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && e->hdt == MA_DTYPE_BF16 && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
+bool fuse_layer(ma_engine* e, int B = 1, int len_override = -1) { return e->opt_fuse_layer && e->bf16 && e->hdt == MA_DTYPE_BF16 && fuse_qkv_attn(e, B, len_override) && fuse_oproj_fc1(e, B, len_override) && e->opt_fuse_fc2; }
 
 // second half of layer l + first half of layer l + 1 in one launch (layer_fused.hpp); belongs to the "cache" class of the profiler
 void enqueue_layer_pair(ma_engine* e, hipStream_t s, int l, const float* resid, int len_override, StepTimer& tm, Rows rw) {
@@ -1366,7 +1366,7 @@ void build_engine(ma_engine* e) {
     e->n_parts = e->bf16 ? gemv_num_blocks<bf16_t>(e->V, c.hidden) : gemv_num_blocks<float>(e->V, c.hidden);
     e->d_pval = e->dmalloc<float>(MB * e->V); e->d_pidx = e->dmalloc<int>(MB * e->V);        // row stride V >= blocks for any rows-per-block
     e->d_st = e->dmalloc<DecState>(MB);
-    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(8);      // [0] error bits (cleared when read), [1] expiries ever, [2] longest slow block (ticks), [3] slow blocks ever, [4] scalar sweeps rescued by a vector look (rows_attn.hpp)
+    e->d_qkv_gran = e->dmalloc<u64>(MB * 3 * H); e->d_chain_err = e->dmalloc<unsigned>(12);      // [0] error bits (cleared when read), [1] expiries ever, [2] longest slow block (ticks), [3] slow blocks ever, [4] scalar sweeps rescued by a vector look (rows_attn.hpp)
     e->d_y1_gran = e->dmalloc<u64>(MB * H);
     HIP_CHECK(hipMemset(e->d_y1_gran, 0, MB * H * sizeof(u64)));
     e->d_attn_pair_gran = e->dmalloc<unsigned long long>(MB * c.heads * ATTN_PAIR_GRANULES);
@@ -1386,7 +1386,7 @@ void build_engine(ma_engine* e) {
     HIP_CHECK(hipMemset(e->d_part_gran, 0, MB * (size_t)c.heads * ATTN_NCHUNK * RF_PART * sizeof(u64)));
 #endif
     HIP_CHECK(hipMemset(e->d_qkv_gran, 0, MB * 3 * H * sizeof(u64)));
-    HIP_CHECK(hipMemset(e->d_chain_err, 0, 8 * sizeof(unsigned)));
+    HIP_CHECK(hipMemset(e->d_chain_err, 0, 12 * sizeof(unsigned)));
     HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_chain_err), sizeof(unsigned)));
     e->d_xb = e->dmalloc<bf16_t>(MB * H); e->d_ffb = e->dmalloc<bf16_t>(MB * c.ffn);
     e->d_ks_o = e->dmalloc<float>(4 * MB * H); e->d_ks_f = e->dmalloc<float>(4 * MB * H);
@@ -1688,14 +1688,15 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "chain_fallbacks") *value = e->chain_fallbacks;
         else if (n == "xchg_last_code") *value = e->xchg_last_code;
         else if (n == "xchg_timeouts" || n == "slow_blocks" || n == "slow_block_max_us" || n == "scalar_sweep_rescues" || n == "xchg_first_giveup_code" ||
-                 n == "xchg_first_giveup_block" || n == "xchg_first_giveup_polls") {
+                 n == "xchg_first_giveup_block" || n == "xchg_first_giveup_polls" || n == "xchg_descheduled") {
             // device counters of the fused launches, never cleared: sweeps that ever gave up | blocks that lived > 1 ms | the longest of them |
-            // scalar sweeps that a vector look had to finish | the first sweep that ever gave up: its error bit, blockIdx.x | y << 8 | z << 16 | wave << 24, its polls
-            unsigned v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // scalar sweeps that a vector look had to finish | the first sweep that ever gave up: its error bit, blockIdx.x | y << 8 | z << 16 | wave << 24, its polls |
+            // sweeps that found 20 ms gone on the clock after a handful of polls (the wave was off the device: common.hpp xchg_expired) and went on
+            unsigned v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipMemcpy(v, e->d_chain_err, sizeof(v), hipMemcpyDeviceToHost));
             *value = n == "xchg_timeouts" ? v[1] : n == "slow_blocks" ? v[3] : n == "scalar_sweep_rescues" ? v[4] : n == "xchg_first_giveup_code" ? (v[5] & 0x7fffffffu)
-                   : n == "xchg_first_giveup_block" ? v[6] : n == "xchg_first_giveup_polls" ? v[7] : v[2] / 100;
+                   : n == "xchg_first_giveup_block" ? v[6] : n == "xchg_first_giveup_polls" ? v[7] : n == "xchg_descheduled" ? v[8] : v[2] / 100;
         }
         else if (n == "resident_blocks") *value = e->resident_blocks;
         else if (n == "use_graph") *value = e->cfg.use_graph;

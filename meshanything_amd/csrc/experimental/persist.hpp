@@ -624,7 +624,7 @@ __global__ __launch_bounds__(PS_THREADS) void persist_decode_kernel(PersistArgs 
     unsigned* ctrl = reinterpret_cast<unsigned*>(ps_smem + PL_CTRL);
     if (tid < 16) ctrl[tid] = 0u;
     __syncthreads();
-    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    u64 t0 = __builtin_amdgcn_s_memrealtime();
     const DecState sv = *a.st;
     const unsigned serial = *a.serial;
 #ifndef ROLE_ONLY

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void qkv_attn_rows_kernel(RowsFusedArgs A) {
     asm volatile("" ::: "memory");
     {
         const int nparts = c == c_last ? 3 : 1;
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         bool done[2] = {w >= B, w + 4 >= B};
         for (;;) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void qkv_attn_rows_kernel(RowsFusedArgs A) {
         const int r = c;
         const gu64* pg = (const gu64*)(A.part_gran + ((size_t)r * nheads + h) * ATTN_NCHUNK * RF_PART);
         constexpr int NG = ATTN_NCHUNK * RF_PART, NL = (NG + 63) / 64;                  // 1056 granules, 17 per lane
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0, pend = (1u << NL) - 1u;
         // a chunk's (m, l) granules are published after its 64 o granules: poll those 32 alone until they are there (see oproj_fc1_rows (3))
         for (;;) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_rows_kernel(RowsFusedArgs A) {
     //      rows in order, so the LAST row is polled alone (the traffic of a batch-1 exchange); once it is complete the earlier rows are, in
     //      practice, too: one pass over them -- still verified tag by tag, nothing relies on the order in which stores become visible ----------
     {
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         bool failed = false;
 #pragma unroll 1
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void oproj_fc1_rows_kernel(RowsFusedArgs A) {
     // ---- (5) all-gather of relu(fc1) for all rows (2048 bf16-pair granules per row, wave w: [512 w, 512 w + 512)): the last row alone first,
     //      then the earlier rows four at a time (see (3)) ---------------------------------------------------------------------------------------
     {
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         bool failed = false;
 #pragma unroll 1

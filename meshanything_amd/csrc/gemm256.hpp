@@ -367,7 +367,7 @@ MA_NO_ASAN __global__ __launch_bounds__(512) void gemm256_kernel(GemmTArgs g, in
             auto exchange = [&](u64* gr) -> float {
                 const float mine = (lsum[tid] + lsum[256 + tid]) + (lsum[512 + tid] + lsum[768 + tid]);
                 ps_publish(gr + (size_t)tile_x * 256, tid, ln.epoch, __float_as_uint(mine));
-                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                u64 t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0;
                 float tot = 0.f;
                 for (int tx = 0; tx < ntx; ++tx) {

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4* __restric
 __global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks, const int* release, unsigned* sink) {
     extern __shared__ char occupy_lds[];
     occupy_lds[threadIdx.x] = 1;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    u64 t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
         if (release && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // the host let go
         __builtin_amdgcn_s_sleep(64);

@@ -166,7 +166,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         constexpr int NK = 16 / NSW;
         const gu64* g64 = (const gu64*)gran + w * NK * 64;
         float* yr = yraw + w * NK * 64;
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0, pend = (1u << NK) - 1u;
         for (;;) {
             u64 v[NK];
@@ -255,7 +255,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             for (int half = 0; half < 2; ++half) {
                 const gu64* g64 = (const gu64*)g2 + w * 1024 + half * 512;
                 float* fr = ffl + w * 1024 + half * 512;
-                const u64 t0 = __builtin_amdgcn_s_memrealtime();
+                u64 t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned spins = 0, pend = 0xffu;
                 for (;;) {
                     u64 v[8];
@@ -290,7 +290,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
         {
             const gu64* g64 = (const gu64*)g2 + w * 512;
             float* fr = ffl + w * 1024;
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            u64 t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0, pend = 0xffu;
             for (;;) {
                 u64 v[8];
@@ -349,7 +349,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
             if (lane == 0) ps_publish(g3, orow, epoch, __float_as_uint(v));
             const gu64* g64 = (const gu64*)g3 + w * 256;
             float* yr = ynext + w * 256;
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            u64 t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0, pend = 0xfu;
             for (;;) {
                 u64 q[4];

@@ -168,7 +168,7 @@ __device__ __forceinline__ void qkv_attn_body(QkvAttnArgs a, const int c, const 
     if (w == 0) {
         const gu64* g64 = (const gu64*)gran;
         const int nparts = c == c_last ? 3 : 1;          // q for everyone; k, v for the block that holds the newest position
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         for (;;) {
             u64 v[3];

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
         const gu64* gq = (const gu64*)(a.qkv_gran + (size_t)b * RA_QKV_GRANULES + h * 32);
         const gu64* p1 = gq + (lane < 32 ? lane : 16 * 32 + (lane - 32));
         const gu64* p2 = gq + 2 * 16 * 32 + (lane & 31);
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         u64 v1, v2;
         for (;;) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             const u64* pp[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { const int c = c0 + i; pp[i] = gq + (size_t)(c >> 2) * 16 * 32 + (c & 3) * 8; }
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            u64 t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0;
             u32x16 g[3];
             for (;;) {
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
             if (lane < 2) __hip_atomic_store(g + 64 + lane, ((u64)epoch << 32) | __float_as_uint(lane == 0 ? M : L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             u64 vo = 0, vm = (u64)epoch << 32;
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            u64 t0 = __builtin_amdgcn_s_memrealtime();
             unsigned spins = 0;
             for (;;) {
                 vo = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512) void rows_attn_kernel(RowsAttnArgs a) {
     __syncthreads();                                        // (xl: every wave is past step C; wave 0 past its hand-over)
     {
         const gu64* ga = (const gu64*)(a.out_gran + (size_t)w * RA_OUT_GRANULES);
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         u64 v[8];
         for (;;) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
     // ---- D: the K quarter of relu(fc1), row `w`: 512 granules; then the fc2 tile ----------------------------------------------------------
     {
         const gu64* ga = (const gu64*)(a.ffn_gran + (size_t)w * RM_FFN_GRANULES + kq * 512);
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         u64 v[8];
         for (;;) {
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void rows_mlp_kernel(RowsMlpArgs a) {
     {   // thread (w, lane): columns 128 w + 2 lane, + 1 of the four quarters: 8 granules
         const int c0 = 128 * w + 2 * lane;
         const gu64* gy = (const gu64*)(a.y2_gran + (size_t)i * RM_Y2_GRANULES + c0);
-        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        u64 t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         u64 v[8];
         for (;;) {

@@ -16,7 +16,8 @@ for st in $STAGES; do
       timeout ${SUITE_TMO:-1200} python -m pytest tests -m gpu -x -q -p no:cacheprovider ${PYTEST_ARGS} 2>&1 | grep -v amdgpu.ids > $O/suite.txt; tail -6 $O/suite.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt ;;
     exp)
-      MA_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_persist.py tests/test_gpu_rows_fused.py tests/test_gpu_rows_attn.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids > $O/suite_experimental.txt; tail -3 $O/suite_experimental.txt ;;
+      MA_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_persist.py tests/test_gpu_rows_fused.py tests/test_gpu_rows_attn.py -x -q -p no:cacheprovider 2>&1 | grep -v amdgpu.ids > $O/suite_experimental.txt; tail -3 $O/suite_experimental.txt
+      MA_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_pipeline.py -x -q -p no:cacheprovider -k "layernorm_finished or kv_written or split_along_k" 2>&1 | grep -v amdgpu.ids > $O/suite_experimental_prefill.txt; tail -3 $O/suite_experimental_prefill.txt ;;
     fp32)
       # the fp32 ("exact") policy on the fused batch-1 chain: bitwise against the five-launch chain, the long-context / reference-anchor gates, one timed mesh each way
       timeout 900 python -m pytest tests/test_gpu_persist.py -x -q -p no:cacheprovider -s -k "fp32 and (fused or fc2)" 2>&1 | grep -v amdgpu.ids > $O/fp32_fused_bitwise.txt; grep -E "A/B|passed|failed|Error|assert" $O/fp32_fused_bitwise.txt | cut -c1-300 | tail -20

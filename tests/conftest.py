@@ -223,22 +223,70 @@ def mouse_variants(golden_dir, k):
     return torch.from_numpy(np.stack(out))
 
 import contextlib
+import gc
+
+_HEALTH = ("chain_fallbacks", "xchg_timeouts", "scalar_sweep_rescues")
+TRANSIENT_FALLBACKS = []            # generations that fell back once and were run again (reported at the end of the session)
+
+
+def _health_note(eng, what, before, after):
+    return (f"{what}: the fused decode launches did not carry this generation (counters before {before}, after {after}, last exchange code "
+            f"{eng.get_option('xchg_last_code')}, first give-up: code {eng.get_option('xchg_first_giveup_code')} block/wave word {eng.get_option('xchg_first_giveup_block'):#x} "
+            f"after {eng.get_option('xchg_first_giveup_polls')} polls, sweeps that restarted their clock {eng.get_option('xchg_descheduled')}, chain_resident "
+            f"{eng.get_option('chain_resident')})")
+
+
+def fused_generate(eng, what, *args, **kw):
+    """`eng.generate(*args, **kw)` whose answer must come from the fused decode launches: a generation whose fused launches time out
+    re-runs on the five-launch chain and returns the same kind of answer, so a test that only looks at the answer can pass on the wrong kernels.  The
+    engine's health counters -- generations that fell back, exchange sweeps that gave up, scalar sweeps that a vector look had to finish -- must not move
+    across the generation whose result is returned, and the fused launches must still be armed after it.
+    One lone give-up per few full-suite runs has been seen since round 5 (never in a soak of one engine; rounds 5 and 6 each one, on different launches):
+    such a generation is run ONCE more with the fused launches re-armed, the event is printed, kept in TRANSIENT_FALLBACKS and listed in the session's
+    summary; a second fall-back in a row fails the test.  Where the device cannot hold the fused grids (chain_resident == 0 from the start) nothing is
+    fused and nothing is checked.  (The fall-back itself has its own tests: test_gpu_persist.py / test_gpu_rows_attn.py, *falls_back*.)"""
+    for attempt in (0, 1):
+        armed = eng.get_option("chain_resident") == 1
+        before = {k: eng.get_option(k) for k in _HEALTH}
+        out = eng.generate(*args, **kw)
+        if not armed:
+            return out
+        after = {k: eng.get_option(k) for k in _HEALTH}
+        if after == before and eng.get_option("chain_resident") == 1:
+            return out
+        note = _health_note(eng, what, before, after)
+        if attempt == 0:
+            TRANSIENT_FALLBACKS.append(note)
+            print(f"\n[fused path] {note} -- re-armed, running this generation once more", flush=True)
+            del out
+            eng.set_option("chain_resident", 1)
+            continue
+        raise AssertionError(note + ": twice in a row; what was verified is the fall-back chain")
+
+
+def pytest_terminal_summary(terminalreporter):
+    if TRANSIENT_FALLBACKS:
+        terminalreporter.section("fused decode launches: generations that fell back once and were re-run")
+        for n in TRANSIENT_FALLBACKS:
+            terminalreporter.line(n)
+
+
+@pytest.fixture(autouse=True)
+def _collect_before_gpu_tests(request):
+    """Engines (and torch tensors) that are only reachable through reference cycles are destroyed when the collector gets round to it: ma_engine_destroy
+    is a string of hipFree calls -- device-wide synchronisations -- and one landing in the middle of a test that holds most of the device with a
+    second stream (the *falls_back* tests) stalls the launches under test until that stream lets go (seen once, round 6).  Collect between tests."""
+    if request.node.get_closest_marker("gpu") is not None:
+        gc.collect()
+    yield
 
 
 @contextlib.contextmanager
 def fused_path_must_hold(eng, what=""):
-    """Parity evidence must be evidence for the launches it names: a generation whose fused decode launches time out re-runs
-    on the five-launch chain and returns the same kind of answer, so a test that only looks at the answer can pass on the wrong kernels.  Wrapped
-    around every generation that is meant to exercise a fused launch: the engine's health counters -- generations that fell back, exchange sweeps
-    that gave up, scalar sweeps that a vector look had to finish -- must not move, and the fused launches must still be armed afterwards.  (The
-    fall-back itself has its own test, tests/test_gpu_fused_chain.py.)  Where the device cannot hold the fused grids (chain_resident == 0 from
-    the start) nothing is fused and nothing is checked."""
-    keys = ("chain_fallbacks", "xchg_timeouts", "scalar_sweep_rescues")
+    """The strict form of fused_generate for a block of several generations: the counters must not move across the block (no second try)."""
     armed = eng.get_option("chain_resident") == 1
-    before = {k: eng.get_option(k) for k in keys}
+    before = {k: eng.get_option(k) for k in _HEALTH}
     yield
     if armed:
-        after = {k: eng.get_option(k) for k in keys}
-        assert after == before and eng.get_option("chain_resident") == 1, (
-            f"{what}: the fused decode launches did not carry this generation (counters before {before}, after {after}, last exchange code "
-            f"{eng.get_option('xchg_last_code')}, chain_resident {eng.get_option('chain_resident')}): what was verified is the fall-back chain")
+        after = {k: eng.get_option(k) for k in _HEALTH}
+        assert after == before and eng.get_option("chain_resident") == 1, _health_note(eng, what, before, after) + ": what was verified is the fall-back chain"

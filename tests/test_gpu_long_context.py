@@ -25,7 +25,7 @@ import pytest
 import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
-from conftest import cached_state_dict, fused_path_must_hold, load_weights_cached, mouse_variants, oracle_device
+from conftest import cached_state_dict, fused_generate, load_weights_cached, mouse_variants, oracle_device
 
 pytestmark = pytest.mark.gpu
 POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}
@@ -93,16 +93,14 @@ def test_full_length_along_the_reference_path(policy, faces, anchor, golden_dir)
     _, prefix = eng.encode(_mouse(golden_dir).cuda())
     assert float(np.abs(prefix[0, :, :8].cpu().numpy() - anchor["long_prefix_cols8"]).max()) < 1e-4      # the engine's own (exact) encoder feeds it
     ref_tok = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
-    with fused_path_must_hold(eng, f"{policy}/{faces} faces, teacher-forced"):
-        toks, lengths, logits = eng.generate(prefix, suppress_eos=True, forced_tokens=ref_tok[None], return_logits=True)
+    toks, lengths, logits = fused_generate(eng, f"{policy}/{faces} faces, teacher-forced", prefix, suppress_eos=True, forced_tokens=ref_tok[None], return_logits=True)
     assert toks.shape == (1, n) and int(lengths[0]) == n and logits.shape[1] == n
     r = _against_anchor(logits[0], anchor, 0, n, policy, f"{policy}/{faces} faces")
     assert torch.equal(toks[0], r["arg"]), "the pick kernel's token is not the argmax of the logits it returned"
     assert r["agree"] >= {"fp32": 0.998, "fp16": 0.985, "bf16": 0.90}[policy], r["agree"]
     del logits
     # free-running: where the engine first leaves the reference's stream, the reference itself must be at a near-tie
-    with fused_path_must_hold(eng, f"{policy}/{faces} faces, free-running"):
-        free, _ = eng.generate(prefix, suppress_eos=True)
+    free, _ = fused_generate(eng, f"{policy}/{faces} faces, free-running", prefix, suppress_eos=True)
     same = (free[0].cpu() == ref_tok)
     fork = int((~same).nonzero()[0]) if not bool(same.all()) else n
     m_fork = float(anchor["long_margin"][fork]) if fork < n else float("inf")
@@ -156,8 +154,8 @@ def test_config5_batched_deep_cache(B, first, anchor, golden_dir):
     load_weights_cached(eng, cfg, init=INIT)
     _, prefix = eng.encode(mouse_variants(golden_dir, B).cuda())
     forced = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
-    with fused_path_must_hold(eng, f"config 5, batch {B}"):      # (8 rows: the two fused launches per layer; 10 rows: the fused two-block attention)
-        toks, lengths, logits = eng.generate(prefix, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(), return_logits=True,
+    # (8 rows: the two fused launches per layer; 10 rows: the fused two-block attention)
+    toks, lengths, logits = fused_generate(eng, f"config 5, batch {B}", prefix, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(), return_logits=True,
                                              logits_first_step=first)
     assert toks.shape == (B, n) and logits.shape == (B, n - first, cfg.vocab) and all(int(l) == n for l in lengths)
     ra = _against_anchor(logits[0], anchor, first, n, policy, f"batch {B}, row 0")
@@ -191,8 +189,7 @@ def test_config3_batch64_deep_cache(anchor, golden_dir):
     _, prefix = eng.encode(x.cuda())
     forced = torch.from_numpy(anchor["long_tokens"][:n].astype(np.int64))
     u = torch.rand(B, n, generator=torch.Generator().manual_seed(640))
-    with fused_path_must_hold(eng, "config 3, batch 64"):
-        toks, lengths, logits = eng.generate(prefix, sampling=True, uniforms=u, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(),
+    toks, lengths, logits = fused_generate(eng, "config 3, batch 64", prefix, sampling=True, uniforms=u, suppress_eos=True, forced_tokens=forced[None].expand(B, -1).contiguous(),
                                              return_logits=True, logits_first_step=first)
     assert toks.shape == (B, n) and logits.shape == (B, n - first, cfg.vocab)
     assert int(toks.min()) >= 0 and int(toks.max()) < cfg.vocab and not bool((toks == 1).any())

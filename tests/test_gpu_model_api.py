@@ -27,7 +27,9 @@ def env():
     model2 = MeshAnything(args)
     res = model2.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     assert list(res.missing_keys) == [] and list(res.unexpected_keys) == []
-    return types.SimpleNamespace(cfg=cfg, model=model2, oracle=Oracle(cfg, sd, "fp32", device=oracle_device()))
+    yield types.SimpleNamespace(cfg=cfg, model=model2, oracle=Oracle(cfg, sd, "fp32", device=oracle_device()))
+    model.engine.close()
+    model2.engine.close()
 
 
 def _clouds(cfg, seeds):

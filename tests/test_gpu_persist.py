@@ -24,7 +24,8 @@ def eng(request, golden_dir):
     x = torch.from_numpy(d["mouse_norm"])[None]
     _, prefix = e.encode(x.cuda())
     e.prefix = prefix
-    return e
+    yield e
+    e.close()                                             # deterministic: a collector-timed ma_engine_destroy (hipFree = device-wide sync) in the middle of a later test stalls it
 
 
 def _need_persist(eng):

@@ -8,7 +8,7 @@ import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
 from meshanything_amd.checkpoint import synthetic_items, synthetic_state_dict
-from conftest import mouse_variants, cached_state_dict, fused_path_must_hold, load_weights_cached, oracle_device
+from conftest import mouse_variants, cached_state_dict, fused_generate, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,9 @@ class Env:
 @pytest.fixture(scope="module", params=["fp32", "bf16", "fp16"])
 def tiny(request):
     cfg = MAConfig.tiny(dtype=POLICIES[request.param], max_batch=4)
-    return Env(cfg, request.param)
+    env = Env(cfg, request.param)
+    yield env
+    env.engine.close()                  # not left to the collector: ma_engine_destroy frees device memory, a device-wide sync wherever it lands
 
 
 def _tol(env, fp32, bf16):
@@ -447,7 +449,8 @@ def full(request):
     env.oracle = Oracle(cfg, env.sd, request.param, device=oracle_device())
     env.engine = Engine(cfg)
     load_weights_cached(env.engine, cfg, init=FULL_INIT)
-    return env
+    yield env
+    env.engine.close()
 
 
 def test_full_encode_and_detok_match_reference_golden(full, golden_dir):
@@ -489,8 +492,7 @@ def test_full_generate_matches_oracle(full, golden_dir):
     x = torch.from_numpy(d["mouse_norm"])[None]
     prefix = full.oracle.process_point_feature(full.oracle.encode_latents(x))
     n = int(os.environ.get("MA_TEST_GEN_TOKENS", "400"))
-    with fused_path_must_hold(full.engine, f"{full.policy} batch 1"):
-        toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+    toks, lengths = fused_generate(full.engine, f"{full.policy} batch 1", prefix.cuda(), max_new_tokens=n, suppress_eos=True)
     v = _check_greedy(full, prefix, toks, lengths, suppress_eos=True)
     nd = assert_diverse(toks, 48, "350M greedy decode")
     print(f"[{full.policy}] {n}-token greedy decode ({nd} distinct ids) vs oracle: {v}")
@@ -505,8 +507,7 @@ def test_full_batched_generate_matches_oracle(full, golden_dir):
     x = mouse_variants(golden_dir, 6)                   # row 0 = mouse.npy itself
     prefix = full.oracle.process_point_feature(full.oracle.encode_latents(x))
     n = 160
-    with fused_path_must_hold(full.engine, f"{full.policy} batch 6"):
-        toks, lengths = full.engine.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True)
+    toks, lengths = fused_generate(full.engine, f"{full.policy} batch 6", prefix.cuda(), max_new_tokens=n, suppress_eos=True)
     assert toks.shape == (6, n)
     v = _check_greedy(full, prefix, toks, lengths, suppress_eos=True)
     nd = [assert_diverse(toks[b], 24, f"batch row {b}") for b in range(6)]
@@ -583,8 +584,7 @@ def test_v2_scale_1600_faces(golden_dir):
     load_weights_cached(env.engine, cfg, init=FULL_INIT)
     x = mouse_variants(golden_dir, 8)
     prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
-    with fused_path_must_hold(env.engine, "1600 faces, batch 8"):
-        toks, lengths = env.engine.generate(prefix.cuda(), max_new_tokens=96, suppress_eos=True)
+    toks, lengths = fused_generate(env.engine, "1600 faces, batch 8", prefix.cuda(), max_new_tokens=96, suppress_eos=True)
     assert toks.shape == (8, 96)
     v = _check_greedy(env, prefix, toks, lengths, suppress_eos=True)
     assert all(r["ambiguous"] <= 8 for r in v), [r["ambiguous"] for r in v]
@@ -724,9 +724,8 @@ def test_prefill_layernorm_finished_inside_the_gemm(golden_dir, policy):
     if eng.get_option("fuse_ln") != 1:
         pytest.skip("the in-launch exchanges are not in use on this device")
     try:
-        with fused_path_must_hold(eng, f"{policy} prefill with fused LayerNorm"):
-            toks, lengths, lg = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
-            t2, _, lg2 = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
+        toks, lengths, lg = fused_generate(eng, f"{policy} prefill with fused LayerNorm", prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
+        t2, _, lg2 = fused_generate(eng, f"{policy} prefill with fused LayerNorm, second run", prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
         assert torch.equal(toks, t2) and torch.equal(lg.view(torch.int32), lg2.view(torch.int32)), "the fused LayerNorm is not bit-stable from launch to launch"
         for b in (0, 21, 42, 63):                                    # (63: its last 64 rows are the tail the row kernel normalises)
             v = verify_greedy_stream(oracle, prefix[b:b + 1], toks[b, :int(lengths[b])].cpu(), GREEDY_TOL[policy], True)

@@ -24,7 +24,7 @@ import torch
 
 from meshanything_amd.checkpoint import synthetic_state_dict
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16, DTYPE_F32
-from conftest import cached_state_dict, fused_path_must_hold, load_weights_cached, oracle_device
+from conftest import cached_state_dict, fused_generate, load_weights_cached, oracle_device
 
 pytestmark = pytest.mark.gpu
 POLICIES = {"fp32": DTYPE_F32, "bf16": DTYPE_BF16, "fp16": DTYPE_F16}
@@ -152,8 +152,8 @@ def test_350m_logits_along_the_reference_path(policy, tag, init, golden_dir):
     sampled = int(a[f"{tag}_mode"][0]) == 1
     forced = torch.from_numpy(ref_tok)[None]
     u = torch.from_numpy(a[f"{tag}_uniforms"])[None]
-    with fused_path_must_hold(eng, f"{policy} reference anchor, batch 1"):        # (16-bit policies: the two fused launches per layer of the batch-1 chain)
-        toks, lengths, logits = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True,
+    # (16-bit policies: the two fused launches per layer of the batch-1 chain)
+    toks, lengths, logits = fused_generate(eng, f"{policy} reference anchor, batch 1", prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True,
                                              sampling=sampled, uniforms=u if sampled else None)
     assert toks.shape == (1, n) and int(lengths[0]) == n
     lg = logits[0]
@@ -234,8 +234,7 @@ def test_350m_batched_decode_along_the_reference_path(policy, B, golden_dir):
     ref_tok = a[f"{tag}_tokens"]
     n = len(ref_tok)
     forced = torch.from_numpy(ref_tok)[None].expand(B, -1).contiguous()
-    with fused_path_must_hold(eng, f"{policy} reference anchor, batch {B}"):
-        toks, lengths, logits = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True)
+    toks, lengths, logits = fused_generate(eng, f"{policy} reference anchor, batch {B}", prefix, max_new_tokens=n, suppress_eos=True, forced_tokens=forced, return_logits=True)
     assert toks.shape == (B, n) and all(int(l) == n for l in lengths)
     top_i = torch.from_numpy(a[f"{tag}_top_idx"]).long().cuda()
     top_v = torch.from_numpy(a[f"{tag}_top_val"]).cuda()

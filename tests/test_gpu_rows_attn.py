@@ -22,7 +22,8 @@ def eng8(request, golden_dir):
     load_weights_cached(e, cfg, init="diverse")
     _, e.prefix = e.encode(mouse_variants(golden_dir, 8).cuda())
     e.policy = request.param
-    return e
+    yield e
+    e.close()
 
 
 def _launches(eng, kv=600):

@@ -33,7 +33,8 @@ def eng(golden_dir):
         pytest.skip("the rows-looped launches are not available on this device (need 256 CUs with 130 KB of LDS each)")
     x = mouse_variants(golden_dir, 8)
     _, e.prefix = e.encode(x.cuda())
-    return e
+    yield e
+    e.close()
 
 
 def _gen(eng, prefix, **kw):
