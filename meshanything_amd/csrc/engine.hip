@@ -160,6 +160,10 @@ struct ma_engine {
     long p_y_part_stride = 0;        // p_y holds up to 4 partial sums of a GEMM split along K (gemm256.hpp GemmSplitK), this many floats apart, for the small prefills that use it
     int opt_fuse_ln = 0;             // (MA_EXPERIMENTAL builds; measured, not kept) prefill: the two LayerNorms of a layer finished inside the out_proj / fc2 GEMMs where those run on whole 256 x 256 tiles (gemm256.hpp LNF form; needs the grid resident like every in-launch exchange: chain_resident)
     u64* d_ln_gran = nullptr; size_t ln_gran_tiles = 0; unsigned ln_epoch = 0;
+    int opt_prefill_tail = 1;        // 16-bit prefill of >= 8 samples: the M % 256 rows behind the 256-row tiles run as a chain of their own on a second stream (prefill())
+    hipStream_t tail_stream_low = nullptr;      // (prefill_tail = 2: the same chain on a stream of the lowest priority -- A/B)
+    hipStream_t tail_stream = nullptr; hipEvent_t tail_fork = nullptr, tail_join = nullptr; std::vector<hipEvent_t> tail_kv;      // its stream; per layer: "the main rows' K / V are in the planes"
+    void* a_patt_tail = nullptr; bf16_t* a_vt_tail = nullptr; size_t vt_tail_elems = 0;      // its attention output (64 rows) and V^T workspace (one sample)
     int opt_gemm_splitk = 1;         // prefill fc2 of small batches as 4 partial sums along K, added up by the LayerNorm that follows (0: never; A/B)
     void *a_feat = nullptr, *a_dataln = nullptr, *a_kv = nullptr, *a_q = nullptr, *a_ln = nullptr, *a_qkv = nullptr, *a_att = nullptr, *a_mlp = nullptr,
          *a_cat = nullptr, *a_mean = nullptr, *a_fein = nullptr, *a_x = nullptr, *a_ph = nullptr, *a_pqkv = nullptr, *a_patt = nullptr, *a_pffn = nullptr;
@@ -270,7 +274,7 @@ struct GemmOut {                       // exactly one of: fp32 stream output | a
 // kv->rows_done = the leading rows for which they did
 struct KvDst { void* k = nullptr; void* v = nullptr; size_t row_stride = 0; int max_seq = 0, T = 0, col0 = 0; int rows_done = 0; };
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const char* bias_name, const float* R, int ldr, GemmOut out,
-          int M, int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr) {
+          int M, int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr, int part = 0) {
     const Entry& en = e->L.get(w);
     const float* bias = bias_name ? e->PF(bias_name) : nullptr;
     hipError_t r;
@@ -279,10 +283,11 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
         GemmTArgs t{};
         t.A = reinterpret_cast<const bf16_t*>(A); t.lda = lda; t.W = reinterpret_cast<const bf16_t*>(e->arena + en.offset); t.bias = bias;
         t.R = R; t.ldr = ldr; t.C = out.c32; t.ldc = out.ld; t.Cb = reinterpret_cast<bf16_t*>(out.act); t.ldcb = out.ld;
-        t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle;
+        t.M = M; t.N = en.rows; t.K = en.cols; t.act = act; t.r_mod = r_mod; t.cmap = out.map; t.xcd_swizzle = e->opt_gemm_xcd_swizzle; t.part = part;
         if (kv) { t.kv_k = reinterpret_cast<bf16_t*>(kv->k); t.kv_v = reinterpret_cast<bf16_t*>(kv->v); t.kv_row_stride = kv->row_stride; t.kv_max_seq = kv->max_seq; t.kv_T = kv->T; t.kv_col0 = kv->col0; }
         r = H16_CALL(e->hdt, HT, launch_gemm_dense<HT>(t, e->n_cus, s, kv ? &kv->rows_done : nullptr, sk, lnf));
     } else {
+        if (part != 0) throw MaError(MA_ERR_INVALID, "internal: a GEMM by row parts needs a 16-bit phase");
         GemmArgs g{};
         g.A = reinterpret_cast<const float*>(A); g.lda = lda; g.W = e->arena + en.offset; g.bias = bias; g.R = R; g.ldr = ldr;
         g.C = out.c32 ? out.c32 : reinterpret_cast<float*>(out.act); g.ldc = out.ld; g.M = M; g.N = en.rows; g.K = en.cols; g.act = act;
@@ -292,8 +297,8 @@ void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string
     if (r != hipSuccess) throw MaError(MA_ERR_HIP, "gemm launch failed for " + w + ": " + hipGetErrorString(r));
 }
 void gemm(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const float* R, int ldr, GemmOut out, int M,
-          int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr) {
-    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod, kv, sk, lnf);
+          int act, int r_mod = 0, KvDst* kv = nullptr, GemmSplitK* sk = nullptr, GemmLnFuse* lnf = nullptr, int part = 0) {
+    gemm(e, s, A, lda, w, b.c_str(), R, ldr, out, M, act, r_mod, kv, sk, lnf, part);
 }
 
 GemmOut to32(float* c, int ld, RowMap m = RowMap{0, 0, 0}) { GemmOut o; o.c32 = c; o.ld = ld; o.map = m; return o; }
@@ -312,9 +317,10 @@ void lnrows(ma_engine* e, hipStream_t s, const float* x, int ldx, const std::str
 // h = LN(h + A W^T + b) for M stacked rows, fp32 in place + 16-bit copy hb (the two post-LN sub-layers of an OPT layer, [3p] OPTDecoderLayer): the GEMM
 // finishes the LayerNorm itself where it can (gemm256.hpp LNF form: whole 256-row tiles of a launch that fills the chip); the row kernel does the rest from
 // the plain sums in `y`.  split: fc2 of small batches may come as partial sums along K instead (GemmSplitK), which the row kernel adds up.
+// part (GemmTArgs::part): 0 = all M rows; 1 = rows [0, M - M % 256); 2 = the rows behind them (A, h, hb, y stay the addresses of row 0)
 void gemm_res_ln(ma_engine* e, hipStream_t s, const void* A, int lda, const std::string& w, const std::string& b, const std::string& ln_prefix, float eps, float* h, void* hb,
-                 float* y, int M, int H, bool allow_split) {
-    const bool fuse = e->opt_fuse_ln && e->dense16 && e->chain_resident && e->d_ln_gran && (size_t)(M / 256) * (size_t)(H / 256) <= e->ln_gran_tiles;
+                 float* y, int M, int H, bool allow_split, int part = 0) {
+    const bool fuse = part == 0 && e->opt_fuse_ln && e->dense16 && e->chain_resident && e->d_ln_gran && (size_t)(M / 256) * (size_t)(H / 256) <= e->ln_gran_tiles;
     GemmSplitK sk;
     sk.max_parts = (allow_split && e->opt_gemm_splitk && e->dense16 && H == 1024 && (long)M * H <= e->p_y_part_stride) ? 4 : 1;
     sk.part_stride = e->p_y_part_stride;
@@ -334,17 +340,25 @@ void gemm_res_ln(ma_engine* e, hipStream_t s, const void* A, int lda, const std:
         }
         return;
     }
-    gemm(e, s, A, lda, w, b, h, H, to32(y, H), M, ACT_NONE, 0, nullptr, &sk);
-    lnrows(e, s, y, H, ln_prefix, eps, h, H, hb, H, M, H, RowMap{0, 0, 0}, RowMap{0, 0, 0}, sk.parts, sk.part_stride, sk.rows);
+    gemm(e, s, A, lda, w, b, h, H, to32(y, H), M, ACT_NONE, 0, nullptr, &sk, nullptr, part);
+    const int Mm = M - M % 256;
+    if (part == 2) {        // (the rows behind the split ones are complete in the first buffer)
+        const size_t r0 = (size_t)Mm;
+        if (M > Mm) lnrows(e, s, y + r0 * H, H, ln_prefix, eps, h + r0 * H, H, reinterpret_cast<char*>(hb) + r0 * H * e->act_elem, H, M - Mm, H);
+        return;
+    }
+    const int rows = part == 1 ? Mm : M;
+    if (rows > 0) lnrows(e, s, y, H, ln_prefix, eps, h, H, hb, H, rows, H, RowMap{0, 0, 0}, RowMap{0, 0, 0}, sk.parts, sk.part_stride, std::min(sk.rows, rows));
 }
 // attention over activation tensors; strides in elements; batch = samples (grid.z)
 void attention(ma_engine* e, hipStream_t s, const void* Q, int q_rs, int q_hs, const void* K, int k_rs, int k_hs, const void* Vp, int v_rs, int v_hs, void* O,
-               int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0) {
+               int o_rs, int Sq, int Sk, int H, int causal_offset, int batch = 1, size_t q_bs = 0, size_t k_bs = 0, size_t v_bs = 0, size_t o_bs = 0, bf16_t* vt = nullptr,
+               size_t vt_elems = 0) {
     AttnArgs a{Q, q_rs, q_hs, K, k_rs, k_hs, Vp, v_rs, v_hs, O, o_rs, Sq, Sk, H, 0.125f, causal_offset, e->dense16 ? 3 : 0};
     a.batch = batch; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     if (e->dense16 && (e->opt_attn_impl == 2 || e->hdt == MA_DTYPE_F16)) {     // (the first-generation kernel, attn_impl 1, is bf16 only)
-        if (attn2_vt_elems(Sk, H, batch) > e->vt_elems) throw MaError(MA_ERR_INVALID, "internal: V^T workspace too small");
-        HIP_CHECK(H16_CALL(e->hdt, HT, launch_attention2<HT>(a, e->a_vt, s)));
+        if (attn2_vt_elems(Sk, H, batch) > (vt ? vt_elems : e->vt_elems)) throw MaError(MA_ERR_INVALID, "internal: V^T workspace too small");
+        HIP_CHECK(H16_CALL(e->hdt, HT, launch_attention2<HT>(a, vt ? vt : e->a_vt, s)));
     } else HIP_CHECK(launch_attention(a, s));
 }
 // fp32 stream rows (row map in, optional row mask) -> activation tensor
@@ -1104,6 +1118,39 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
     float* y = e->p_y;                       // (B*T, H)
     void* ffn = e->a_pffn;                   // (B*T, ffn) activation
     const size_t kv_row_elems = e->kv_row_bytes / e->kv_elem;
+    // The last rows as a chain of their own (round 6).  M = B x 257 leaves M % 256 = B rows behind the 256-row tiles, and every GEMM of a layer ran them as a
+    // launch of its own behind its tiles (the skinny GEMM: 6.5 us at 16 rows, 11 us at 64; with the K / V copy of those rows 25 - 47 us per layer = 9 - 12 % of the
+    // prefill).  Those rows are the LAST B positions of the LAST sample: causal attention means no other row ever reads anything of theirs, so the rows in
+    // front of them (`part 1`: exact tile rows, no tail launches) run all 24 layers without them, and they (`part 2`) follow on a second stream with the same
+    // kernels the one-stream form gives them -- each of their layers needs from the main chain only that layer's K / V of the earlier positions (one event
+    // per layer).  The main chain's attention still launches over all B x T query rows: the last B of them are stale rows of the q|k|v buffer, their output
+    // goes to rows of `att` nobody reads (the tail chain has its own), and what they do to keys they can see but that the tail chain is still writing is
+    // masked in every valid row (the planes are zeroed at creation, so a masked V is a finite number).  Same bits as the one-stream form.
+    const int Mm = M - M % 256;
+    const bool tail = e->opt_prefill_tail && e->bf16 && B >= 8 && M > Mm && M - Mm <= 64 && M - Mm <= T && e->a_patt_tail && attn2_vt_elems(T, c.heads, 1) <= e->vt_tail_elems;
+    hipStream_t s2 = nullptr;
+    if (tail) {
+        if (!e->tail_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&e->tail_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&e->tail_join, hipEventDisableTiming));
+            e->tail_kv.resize(c.layers);
+            for (hipEvent_t& ev : e->tail_kv) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        s2 = e->tail_stream;
+        if (e->opt_prefill_tail == 2) {
+            if (!e->tail_stream_low) {
+                int lo = 0, hi = 0;
+                HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));            // (numerically: lo >= hi; lo = the least urgent)
+                HIP_CHECK(hipStreamCreateWithPriority(&e->tail_stream_low, hipStreamNonBlocking, lo));
+            }
+            s2 = e->tail_stream_low;
+        }
+        HIP_CHECK(hipEventRecord(e->tail_fork, s));              // the embedded rows (h, hb) of every row are there
+        HIP_CHECK(hipStreamWaitEvent(s2, e->tail_fork, 0));
+    }
+    const int mp = tail ? 1 : 0;                                     // the main chain's row part
+    const int Mk = tail ? Mm : M;                                    // rows whose K / V the main chain puts into the planes
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = DEC + "layers." + std::to_string(l) + ".";
         if (e->bf16) {
@@ -1111,12 +1158,30 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
             // the rows behind them (the 64-row tail of M = B x 257; every row when another kernel took the GEMM) are copied from the q|k|v tensor.
             // Attention then reads K, and the V^T packing V, from the planes: the cache IS the prefill's K / V operand.
             KvDst kv; kv.k = e->kplane(row0, l); kv.v = e->vplane(row0, l); kv.row_stride = kv_row_elems; kv.max_seq = e->maxseq; kv.T = T; kv.col0 = H;
-            gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE, 0, e->opt_qkv_to_cache ? &kv : nullptr);
-            if (kv.rows_done < M) {
-                const long n = (long)(M - kv.rows_done) * c.heads * 8;
-                hipLaunchKernelGGL((kv_fill_rows_kernel<bf16_t, bf16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, kv.rows_done, M, T,
+            gemm(e, s, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE, 0, e->opt_qkv_to_cache ? &kv : nullptr, nullptr, nullptr, mp);
+            auto kv_fill = [&](hipStream_t st, int r_begin, int r_end) {
+                const long n = (long)(r_end - r_begin) * c.heads * 8;
+                hipLaunchKernelGGL((kv_fill_rows_kernel<bf16_t, bf16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(qkv), 3 * H, H, 2 * H, r_begin, r_end, T,
                                    c.heads, e->maxseq, reinterpret_cast<bf16_t*>(kv.k), reinterpret_cast<bf16_t*>(kv.v), kv_row_elems);      // a copy of 16-bit words: either format
                 HIP_CHECK(hipGetLastError());
+            };
+            if (kv.rows_done < Mk) kv_fill(s, kv.rows_done, Mk);
+            if (tail) {
+                // ---- the tail chain's layer l (stream s2): enqueued here, between the main chain's q|k|v and its attention ----
+                HIP_CHECK(hipEventRecord(e->tail_kv[l], s));
+                KvDst kv2 = kv;
+                gemm(e, s2, hb, H, p + "qkv.weight", p + "qkv.bias", nullptr, 0, toact(qkv, 3 * H), M, ACT_NONE, 0, e->opt_qkv_to_cache ? &kv2 : nullptr, nullptr, nullptr, 2);
+                kv_fill(s2, Mm, M);
+                HIP_CHECK(hipStreamWaitEvent(s2, e->tail_kv[l], 0));
+                const int nt = M - Mm;                               // its rows: positions T - nt .. T - 1 of sample B - 1
+                void* att_t = e->a_patt_tail;
+                attention(e, s2, aoff(e, qkv, (size_t)Mm * 3 * H), 3 * H, 64, e->kplane(row0 + B - 1, l), 64, e->maxseq * 64, e->vplane(row0 + B - 1, l), 64, e->maxseq * 64, att_t, H, nt, T,
+                          c.heads, T - nt, 1, 0, 0, 0, 0, e->a_vt_tail, e->vt_tail_elems);
+                // (row m of the A operand is read at A + m * lda: the address row 0 WOULD have)
+                const void* att_t0 = reinterpret_cast<const char*>(att_t) - (size_t)Mm * H * e->act_elem;
+                gemm_res_ln(e, s2, att_t0, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, e->opt_gemm_splitk >= 2, 2);
+                gemm(e, s2, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU, 0, nullptr, nullptr, nullptr, 2);
+                gemm_res_ln(e, s2, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", p + "final_layer_norm.", 1e-5f, h, hb, y, M, H, true, 2);
             }
             attention(e, s, qkv, 3 * H, 64, kv.k, 64, e->maxseq * 64, kv.v, 64, e->maxseq * 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, kv_row_elems, kv_row_elems, (size_t)T * H);
         } else {
@@ -1128,11 +1193,15 @@ void prefill(ma_engine* e, hipStream_t s, const float* prefix, int row0, int B) 
             attention(e, s, qkv, 3 * H, 64, aoff(e, qkv, H), 3 * H, 64, aoff(e, qkv, 2 * H), 3 * H, 64, att, H, T, T, c.heads, 0, B, (size_t)T * 3 * H, (size_t)T * 3 * H,
                       (size_t)T * 3 * H, (size_t)T * H);
         }
-        gemm_res_ln(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, e->opt_gemm_splitk >= 2);
-        gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU);
+        gemm_res_ln(e, s, att, H, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", p + "self_attn_layer_norm.", 1e-5f, h, hb, y, M, H, e->opt_gemm_splitk >= 2, mp);
+        gemm(e, s, hb, H, p + "fc1.weight", p + "fc1.bias", nullptr, 0, toact(ffn, c.ffn), M, ACT_RELU, 0, nullptr, nullptr, nullptr, mp);
         // small batches: fc2's 256 x 256 tiles (N = hidden: four per tile row) fill a fraction of the chip while each runs 64 K-tiles -- split along K
         // into partial sums that the LayerNorm adds up (gemm256.hpp GemmSplitK; 16 samples: 64 tiles x 4 parts = one round of 16 K-tiles)
-        gemm_res_ln(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", p + "final_layer_norm.", 1e-5f, h, hb, y, M, H, true);
+        gemm_res_ln(e, s, ffn, c.ffn, p + "fc2.weight", p + "fc2.bias", p + "final_layer_norm.", 1e-5f, h, hb, y, M, H, true, mp);
+    }
+    if (tail) {
+        HIP_CHECK(hipEventRecord(e->tail_join, s2));
+        HIP_CHECK(hipStreamWaitEvent(s, e->tail_join, 0));
     }
     // only the last prefix row of every sample feeds lm_head (the reference computes all 257 rows and discards 256, shape_opt.py:155)
     enqueue_lm_head(e, s, h + (size_t)(T - 1) * H, T * H, nullptr, nullptr, none, Rows{row0, B});
@@ -1485,6 +1554,10 @@ void build_engine(ma_engine* e) {
         e->d_ln_gran = e->dmalloc<u64>(2 * e->ln_gran_tiles * 256);
         HIP_CHECK(hipMemset(e->d_ln_gran, 0, 2 * e->ln_gran_tiles * 256 * sizeof(u64)));
         e->a_ph = amalloc(PR * H); e->a_pqkv = amalloc(PR * 3 * H); e->a_patt = amalloc(PR * H); e->a_pffn = amalloc(PR * c.ffn);
+        if (e->bf16) {
+            e->a_patt_tail = amalloc((size_t)64 * H);
+            e->vt_tail_elems = attn2_vt_elems(T, c.heads, 1); e->a_vt_tail = e->dmalloc<bf16_t>(e->vt_tail_elems);
+        }
     }
     const size_t B = c.max_batch;
     e->w_latents = e->dmalloc<float>(B * T * W); e->w_prefix = e->dmalloc<float>(B * T * H);
@@ -1562,6 +1635,11 @@ void ma_engine_destroy(ma_engine* e) {
     (void)hipSetDevice(e->device);
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
+    if (e->tail_stream_low) (void)hipStreamDestroy(e->tail_stream_low);
+    if (e->tail_fork) (void)hipEventDestroy(e->tail_fork);
+    if (e->tail_join) (void)hipEventDestroy(e->tail_join);
+    for (hipEvent_t ev : e->tail_kv) (void)hipEventDestroy(ev);
     for (hipStream_t st : e->grp_stream) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : e->grp_done) (void)hipEventDestroy(ev);
     if (e->grp_fork) (void)hipEventDestroy(e->grp_fork);
@@ -1629,6 +1707,7 @@ int ma_engine_set_option(ma_engine* e, const char* name, int64_t value) {
         else if (n == "attn_final_waves") { if (value != 0 && value != 4 && value != 8 && value != 16) throw MaError(MA_ERR_INVALID, "attn_final_waves: 0, 4, 8 or 16"); e->opt_attn_final_waves = (int)value; drop_graphs(e); }
         else if (n == "gemm_xcd_swizzle") e->opt_gemm_xcd_swizzle = (int)value;
         else if (n == "qkv_to_cache") e->opt_qkv_to_cache = value ? 1 : 0;
+        else if (n == "prefill_tail") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "prefill_tail: 0 (one stream), 1 (the last rows as a chain on a second stream), 2 (... of the lowest priority)"); e->opt_prefill_tail = (int)value; }
         else if (n == "gemm_splitk") { if (value < 0 || value > 2) throw MaError(MA_ERR_INVALID, "gemm_splitk: 0 (never), 1 (fc2 of small prefills), 2 (+ out_proj)"); e->opt_gemm_splitk = (int)value; }
         else if (n == "fuse_ln") {
 #ifndef MA_EXPERIMENTAL
@@ -1730,6 +1809,7 @@ int ma_engine_get_option(ma_engine* e, const char* name, int64_t* value) {
         else if (n == "gemm_xcd_swizzle") *value = e->opt_gemm_xcd_swizzle;
         else if (n == "qkv_to_cache") *value = e->opt_qkv_to_cache;
         else if (n == "gemm_splitk") *value = e->opt_gemm_splitk;
+        else if (n == "prefill_tail") *value = e->opt_prefill_tail;
         else if (n == "fuse_ln") *value = e->opt_fuse_ln && e->chain_resident;      // (effective)
         else if (n == "attn_impl") *value = e->opt_attn_impl;
         else if (n == "gemm_variant") *value = gemm_tile_variant();

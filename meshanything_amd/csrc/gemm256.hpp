@@ -767,6 +767,27 @@ inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
     // the 256-row tile's 16-bit-only epilogue (C == nullptr) carries no residual and stores 16 bytes to Cb: such calls take the 128-row tile
     const bool tile256_ok = !(g.R && !g.C) && (!g.Cb || g.ldcb % 8 == 0);
+    // rows [r0, r0 + rows) on the small kernels: the skinny matrix-core GEMM of the batched decode step (`dec`), else the 128-row tiles in the shape that
+    // `choice_rows` rows would get (the stretch these rows belong to in the call that computes everything)
+    auto rows_on_small = [&](size_t r0, int rows, bool dec, int choice_rows) -> hipError_t {
+        if (dec) {
+            GemmDecArgs d{};
+            d.W = g.W; d.bias = g.bias; d.xb = g.A + r0 * g.lda; d.xb_stride = g.lda; d.N = g.N; d.K = g.K; d.B = rows; d.act = g.act; d.epi = EPI_PLAIN; d.ksplit = 1;
+            if (g.R) { d.res = g.R + r0 * g.ldr; d.res_stride = g.ldr; }
+            if (g.C) { d.y = g.C + r0 * g.ldc; d.y_stride = g.ldc; }
+            if (g.Cb) { d.yb = g.Cb + r0 * g.ldcb; d.yb_stride = g.ldcb; }
+            return launch_gemm_dec<HT>(d, s);
+        }
+        GemmTArgs t = g;
+        t.A = g.A + r0 * g.lda; t.M = rows;
+        if (g.R) t.R = g.R + r0 * g.ldr;
+        t.C = g.C ? g.C + r0 * g.ldc : nullptr;
+        t.Cb = g.Cb ? g.Cb + r0 * g.ldcb : nullptr;
+        return launch_gemm_tile<HT>(t, s, choice_rows);
+    };
+    const int part = g.part;
+    const int Mm = g.M - g.M % 256;                                  // parts 1 | 2 meet here
+    if (part != 0 && (g.cmap.grp != 0 || g.r_mod != 0 || lnf)) return hipErrorInvalidValue;
     if (tile256_ok && gemm256_enabled() && n_cus > 0 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256 && g.M >= 256 && (long)((g.N + 255) / 256) * ((g.M + 255) / 256) < (1L << 24)) {
         const int ntx = (g.N + 255) / 256;
         const bool can_split = g.cmap.grp == 0 && g.r_mod == 0;
@@ -814,7 +835,7 @@ inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_
 #ifdef MA_EXPERIMENTAL
             const bool do_ln = lnf && ks == 1 && gemm256_enabled() >= 2 && can_split && g.C && g.act == ACT_NONE && g.N % 256 == 0 && lnf->ln.gran && lnf->ln.gamma && lnf->ln.beta &&
                                lnf->ln.err && lnf->ln.epoch != 0 && g_ln.C && g_ln.ldc % 4 == 0 && (!g_ln.Cb || g_ln.ldcb % 4 == 0);
-            if (do_ln) {
+            if (do_ln && part != 2) {
                 lnf->rows = nty * 256;
                 GemmTArgs ml = g_ln;
                 ml.M = nty * 256;
@@ -827,40 +848,29 @@ inline hipError_t launch_gemm_dense_impl(const GemmTArgs& g, const GemmTArgs& g_
 #endif
             if (ks > 1) {
                 sk->parts = ks; sk->rows = nty * 256;
-                hipError_t r = g256_launch<HT, ACT_NONE>(m, nty, ntx, s, ks, sk->part_stride);
+                hipError_t r = part == 2 ? hipSuccess : g256_launch<HT, ACT_NONE>(m, nty, ntx, s, ks, sk->part_stride);
                 if (r != hipSuccess) return r;
             }
             const bool kv = ks == 1 && persist && kv_rows && g.kv_k && g.kv_v && g.act == ACT_NONE && g.kv_T >= 8 && g.kv_col0 % 64 == 0 && g.N == 3 * g.kv_col0;
             if (kv) {
                 *kv_rows = nty * 256;
-                hipError_t r = g256p_launch<HT, ACT_NONE, true>(m, nty, ntx, n_cus, s);
+                hipError_t r = part == 2 ? hipSuccess : g256p_launch<HT, ACT_NONE, true>(m, nty, ntx, n_cus, s);
                 if (r != hipSuccess) return r;
             }
-            hipError_t r = (kv || ks > 1 || do_ln) ? hipSuccess : persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
+            hipError_t r = (kv || ks > 1 || do_ln || part == 2) ? hipSuccess : persist ? (g.act == ACT_RELU ? g256p_launch<HT, ACT_RELU>(m, nty, ntx, n_cus, s) : g.act == ACT_GELU ? g256p_launch<HT, ACT_GELU>(m, nty, ntx, n_cus, s)
                                                                                                                              : g256p_launch<HT, ACT_NONE>(m, nty, ntx, n_cus, s))
                                    : (g.act == ACT_RELU ? g256_launch<HT, ACT_RELU>(m, nty, ntx, s) : g.act == ACT_GELU ? g256_launch<HT, ACT_GELU>(m, nty, ntx, s) : g256_launch<HT, ACT_NONE>(m, nty, ntx, s));
             const int rest = can_split ? g.M - nty * 256 : 0;
             if (r != hipSuccess || rest == 0) return r;
-            const size_t r0 = (size_t)nty * 256;
-            // (with lnf: g.C is the caller's tail buffer and g.Cb null -- the rows behind the tiles leave as plain sums, their LayerNorm is the caller's row kernel)
-            float* const tailC = g.C;
-            bf16_t* const tailCb = g.Cb;
-            if (rest <= 64 && g.K % 128 == 0) {
-                GemmDecArgs d{};
-                d.W = g.W; d.bias = g.bias; d.xb = g.A + r0 * g.lda; d.xb_stride = g.lda; d.N = g.N; d.K = g.K; d.B = rest; d.act = g.act; d.epi = EPI_PLAIN; d.ksplit = 1;
-                if (g.R) { d.res = g.R + r0 * g.ldr; d.res_stride = g.ldr; }
-                if (tailC) { d.y = tailC + r0 * g.ldc; d.y_stride = g.ldc; }
-                if (tailCb) { d.yb = tailCb + r0 * g.ldcb; d.yb_stride = g.ldcb; }
-                return launch_gemm_dec<HT>(d, s);
-            }
-            GemmTArgs t = g;
-            t.A = g.A + r0 * g.lda; t.M = rest;
-            if (g.R) t.R = g.R + r0 * g.ldr;
-            t.C = tailC ? tailC + r0 * g.ldc : nullptr;
-            t.Cb = tailCb ? tailCb + r0 * g.ldcb : nullptr;
-            return launch_gemm_tile<HT>(t, s);
+            // the rows behind the tiles: <= 64 of them on the skinny GEMM, more on the 128-row tiles (with lnf: g.C is the caller's tail buffer and g.Cb null -- they
+            // leave as plain sums, their LayerNorm is the caller's row kernel); a call for part 1 | 2 runs the stretch of them on its side of Mm
+            const bool dec = rest <= 64 && g.K % 128 == 0;
+            const int rb = part == 2 ? std::max(nty * 256, Mm) : nty * 256, re = part == 1 ? Mm : g.M;
+            return re > rb ? rows_on_small((size_t)rb, re - rb, dec, rest) : hipSuccess;
         }
     }
+    if (part == 1) return Mm > 0 ? rows_on_small(0, Mm, false, g.M) : hipSuccess;
+    if (part == 2) return g.M > Mm ? rows_on_small((size_t)Mm, g.M - Mm, false, g.M) : hipSuccess;
     return launch_gemm_tile<HT>(g, s);
 }
 

@@ -42,6 +42,9 @@ struct GemmTArgs {
     // fused q|k|v projection writes its K and V columns -- [kv_col0, 2 kv_col0) and [2 kv_col0, 3 kv_col0), heads of 64 -- straight into the KV-cache
     // planes instead of Cb: logical row m = sample m / kv_T, position m % kv_T -> plane[sample * kv_row_stride + (head * kv_max_seq + position) * 64 + d]
     bf16_t* kv_k; bf16_t* kv_v; size_t kv_row_stride; int kv_max_seq, kv_T, kv_col0;
+    // launch_gemm_dense only: which rows this call computes -- 0 = all; 1 = rows [0, M - M % 256); 2 = the M % 256 rows behind them.  The kernels are chosen
+    // as for the whole problem, so 1 and 2 together write exactly what 0 writes (the prefill runs its last rows as a chain of their own on a second stream)
+    int part;
 };
 
 // MA_NO_ASAN: the LDS-DMA kernels stay uninstrumented in the sanitizer build (MA_DEBUG=asan): device ASan lowers a kernel's LDS to global
@@ -216,11 +219,14 @@ inline hipError_t gt_launch(const GemmTArgs& g, hipStream_t s) {
 }
 
 // 16-byte DMA sources and vector epilogue accesses need: lda % 8 == 0, K % 32 == 0, ldc / ldr % 4 == 0, ldcb % 4 == 0
+// choice_rows > 0: the tile shape is chosen as for a problem of that many rows (a stretch of a larger problem's rows computed by a call of its own gets the
+// larger problem's kernel, hence its bits: launch_gemm_dense, GemmTArgs::part); the grid always comes from the real row count
 template <typename HT>
-inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
+inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s, int choice_rows = 0) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    const int Msel = choice_rows > 0 ? choice_rows : g.M;
     if (g.K % 32 != 0 || g.lda % 8 != 0 || (g.C && g.ldc % 4) || (g.R && g.ldr % 4) || (g.Cb && g.ldcb % 4) || (!g.C && !g.Cb)) return hipErrorInvalidValue;
-    const long tiles128 = (long)((g.N + 127) / 128) * ((g.M + 127) / 128);
+    const long tiles128 = (long)((g.N + 127) / 128) * ((Msel + 127) / 128);
     const int v = gemm_tile_variant();
 #ifdef MA_EXPERIMENTAL
     // the A/B variants of rounds 2-3 (profiles/r02_ab_gemm_tile_stages.txt, r03_ab_gemm_tile_occupancy_and_tail.txt): evidence, not product
@@ -251,10 +257,10 @@ inline hipError_t launch_gemm_tile(const GemmTArgs& g, hipStream_t s) {
     // per CU) -- a third less LDS fill per FLOP.  Isolated: 569 vs 504 TFLOP/s (67648 x 3072 x 768), 602 vs 514 (262144 x 1536 x 768), 983 vs
     // 720-868 on 8192^3 (profiles/r03_ab_gemm_tile_occupancy_and_tail.txt); inside the pipeline the detokenizer gains 2.6 %, the encoder's
     // 262144-row GEMM loses (profiles/r03_ab_dense_gemm_selection_in_pipeline.txt), so it is kept to 2048 .. 16384 tiles of M <= 131072.
-    if (g.K % 64 == 0 && g.M > 128 && g.M <= 131072 && g.N > 64 && tiles128 >= 2048) return gt_launch<HT, 256, 128, 64, 3, true, 4, 2>(g, s);
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 64 && tiles128 >= 160) return gt_launch<HT, 128, 128, 64, 2, true>(g, s);
+    if (g.K % 64 == 0 && Msel > 128 && Msel <= 131072 && g.N > 64 && tiles128 >= 2048) return gt_launch<HT, 256, 128, 64, 3, true, 4, 2>(g, s);
+    if (g.K % 64 == 0 && Msel > 64 && g.N > 64 && tiles128 >= 160) return gt_launch<HT, 128, 128, 64, 2, true>(g, s);
     // the 128 x 128 grid would leave a third of the CUs idle: halve the tile along N
-    if (g.K % 64 == 0 && g.M > 64 && g.N > 32) return gt_launch<HT, 128, 64, 64, 2, true>(g, s);
+    if (g.K % 64 == 0 && Msel > 64 && g.N > 32) return gt_launch<HT, 128, 64, 64, 2, true>(g, s);
     return gt_launch<HT, 64, 64, 32, 2>(g, s);
 }
 

@@ -667,6 +667,40 @@ def test_prefill_kv_written_by_the_qkv_gemm_equals_the_copy(golden_dir, policy):
     eng.close()
 
 
+@pytest.mark.parametrize("policy,B", [("bf16", 64), ("fp16", 64), ("bf16", 16), ("bf16", 24), ("bf16", 8), ("fp16", 40)])
+def test_prefill_last_rows_as_their_own_chain_equal_the_one_stream_form(golden_dir, policy, B):
+    """Round 6: M = B x 257 leaves B rows behind the 256-row tiles -- the last B positions of the last sample, which no other row ever reads (causal
+    attention).  With option prefill_tail (default 1) they run all 24 layers as a chain of their own on a second stream, fed per layer with the main
+    chain's K / V through one event, with the kernels the one-stream form gives them (csrc/engine.hip prefill, gemm256.hpp GemmTArgs::part).  The
+    logits of the prefill's token and of decode steps that read every cached position -- the last sample's most of all -- must be the one-stream
+    form's bit for bit (every stretch of rows gets the kernel the one-stream form gives it: the skinny GEMM behind 256-row tiles, the 128-row tiles in
+    the whole problem's shape where that form runs everything on them -- out_proj at 16 / 24 samples), and bit-stable from run to run."""
+    from meshanything_amd.engine import Engine
+    n = 12
+    cfg = MAConfig.full(dtype=POLICIES[policy], max_batch=B)
+    eng = Engine(cfg)
+    load_weights_cached(eng, cfg, init=FULL_INIT)
+    g = torch.Generator().manual_seed(17)
+    prefix = (torch.randn(B, cfg.num_latents + 1, cfg.hidden, generator=g) * 0.5).cuda()
+    assert eng.get_option("prefill_tail") == 1
+    runs = {}
+    try:
+        for mode in (1, 0, 1, 1):
+            eng.set_option("prefill_tail", mode)
+            t, _, lg = eng.generate(prefix, max_new_tokens=n, suppress_eos=True, return_logits=True)
+            runs.setdefault(mode, []).append((t.clone(), lg.clone()))
+    finally:
+        eng.set_option("prefill_tail", 1)
+    two, one = runs[1], runs[0][0]
+    assert_diverse(one[0], 8, "one-stream reference stream")
+    for t, lg in two[1:]:
+        assert torch.equal(two[0][0], t) and torch.equal(two[0][1].view(torch.int32), lg.view(torch.int32)), "the two-stream prefill is not bit-stable from run to run"
+    assert torch.equal(one[0], two[0][0]), "tokens differ between the one-stream and the two-stream prefill"
+    assert torch.equal(one[1].view(torch.int32), two[0][1].view(torch.int32)), \
+        f"logits differ between the one-stream and the two-stream prefill: max {float((one[1] - two[0][1]).abs().max()):.3e}"
+    eng.close()
+
+
 @pytest.mark.parametrize("policy", ["bf16", "fp16"])
 def test_prefill_of_16_samples_with_fc2_split_along_k(golden_dir, policy):
     """Round 6: at 16 samples (M = 4 112) the prefill's fc2 -- N = 1024: 64 tiles of 256 x 256, each 64 K-tiles deep -- runs as FOUR partial sums along
