@@ -160,8 +160,10 @@ struct ma_engine {
     long p_y_part_stride = 0;        // p_y holds up to 4 partial sums of a GEMM split along K (gemm256.hpp GemmSplitK), this many floats apart, for the small prefills that use it
     int opt_fuse_ln = 0;             // (MA_EXPERIMENTAL builds; measured, not kept) prefill: the two LayerNorms of a layer finished inside the out_proj / fc2 GEMMs where those run on whole 256 x 256 tiles (gemm256.hpp LNF form; needs the grid resident like every in-launch exchange: chain_resident)
     u64* d_ln_gran = nullptr; size_t ln_gran_tiles = 0; unsigned ln_epoch = 0;
-    int opt_prefill_tail = 1;        // 16-bit prefill of >= 8 samples: the M % 256 rows behind the 256-row tiles run as a chain of their own on a second stream (prefill())
-    hipStream_t tail_stream_low = nullptr;      // (prefill_tail = 2: the same chain on a stream of the lowest priority -- A/B)
+    int opt_prefill_tail = 2;        // 16-bit prefill of >= 8 samples: the M % 256 rows behind the 256-row tiles run as a chain of their own on a second stream (prefill());
+                                     // 2 (default): that stream has the lowest priority -- HIP keeps a pool of hardware queues per priority, so it can never land on the
+                                     // hardware queue of the main stream (or of the application's default-priority streams), where it would run IN LINE with them; 1: default priority
+    hipStream_t tail_stream_low = nullptr;      // (prefill_tail = 2)
     hipStream_t tail_stream = nullptr; hipEvent_t tail_fork = nullptr, tail_join = nullptr; std::vector<hipEvent_t> tail_kv;      // its stream; per layer: "the main rows' K / V are in the planes"
     void* a_patt_tail = nullptr; bf16_t* a_vt_tail = nullptr; size_t vt_tail_elems = 0;      // its attention output (64 rows) and V^T workspace (one sample)
     int opt_gemm_splitk = 1;         // prefill fc2 of small batches as 4 partial sums along K, added up by the LayerNorm that follows (0: never; A/B)

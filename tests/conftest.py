@@ -271,6 +271,39 @@ def pytest_terminal_summary(terminalreporter):
             terminalreporter.line(n)
 
 
+def generate_on_a_starved_device(eng, gen, cus=224, attempts=5):
+    """`gen()` (a generation on the fused decode launches) while `cus` CUs are held by a second stream for up to 2 s: returns (result, seconds, warnings
+    caught).  The engine must notice the starved grid (one bounded sweep), fall back and say so with a RuntimeWarning.
+    The second stream has to sit on a hardware queue of its own for that: HIP multiplexes a process's streams onto a few hardware queues (four by default),
+    in order of creation, and a stream of the engine (its main one; since round 6 also the prefill's tail-chain stream) that shares a queue with the hog's
+    simply waits behind it -- the generation then takes the hog's 2 s and meets an idle device: no time-out, nothing to fall back from (seen in full-suite
+    runs, where dozens of streams have come and gone).  So: a fresh side stream per attempt, all kept alive so that the next one lands on the next queue."""
+    import time, warnings
+    import torch
+    kept = []
+    for k in range(attempts):
+        side = torch.cuda.Stream()
+        kept.append(side)
+        release = torch.zeros(1, dtype=torch.int32).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        eng.occupy_cus(cus, 2_000_000, stream=side, release=release)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            try:
+                out = gen()
+            finally:
+                release[0] = 1
+        dt = time.time() - t0
+        side.synchronize()
+        torch.cuda.synchronize()
+        if any("fused decode launches timed out" in str(w.message) for w in caught):
+            return out, dt, caught
+        print(f"[starved device] attempt {k}: no time-out in {dt:.2f} s -- an engine stream shared the hog's hardware queue and waited behind it; another side stream", flush=True)
+        eng.set_option("chain_resident", 1)
+    pytest.fail(f"the fused launches never timed out under a {cus}-CU hog in {attempts} attempts")
+
+
 @pytest.fixture(autouse=True)
 def _collect_before_gpu_tests(request):
     """Engines (and torch tensors) that are only reachable through reference cycles are destroyed when the collector gets round to it: ma_engine_destroy

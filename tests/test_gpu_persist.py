@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16
-from conftest import cached_state_dict, load_weights_cached
+from conftest import cached_state_dict, generate_on_a_starved_device, load_weights_cached
 
 pytestmark = pytest.mark.gpu
 
@@ -200,22 +200,10 @@ def test_fused_launches_fall_back_when_the_device_is_shared(eng):
     want, want_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
     want = want.cpu()
     base = eng.get_option("chain_fallbacks")
-    import time
-    side = torch.cuda.Stream()
-    release = torch.zeros(1, dtype=torch.int32).pin_memory()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    # 224 of the 256 CUs are gone until `release` is set: the prefill runs on the 32 that are left (1/8 of the chip), the first fused decode
+    # 224 of the 256 CUs are gone until the helper lets go: the prefill runs on the 32 that are left (1/8 of the chip), the first fused decode
     # launch then cannot get its 256 blocks resident.  (Measured, profiles/r03_diag_stream_concurrency.txt: a 128-CU hog changes nothing --
     # 256 blocks still fit; a 250-CU hog starves every kernel of the other stream until it ends.)
-    eng.occupy_cus(224, 2_000_000, stream=side, release=release)
-    try:
-        with pytest.warns(RuntimeWarning, match="fused decode launches timed out"):       # the Python handle says so, once per event
-            got, got_len = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)      # must not raise
-    finally:
-        release[0] = 1
-    t1 = time.time()
-    torch.cuda.synchronize()
+    (got, got_len), dt, _ = generate_on_a_starved_device(eng, lambda: eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True))      # must not raise; must warn
     try:
         assert eng.get_option("chain_fallbacks") == base + 1, "the starved grid was not noticed"
         assert eng.get_option("chain_resident") == 0 and eng.get_option("fuse_qkv_attn") == 0 and eng.get_option("fuse_oproj_fc1") == 0
@@ -223,9 +211,8 @@ def test_fused_launches_fall_back_when_the_device_is_shared(eng):
         # the engine stays on the five-launch chain (no spinning on a device that has shown to be shared): still the same tokens
         again, _ = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)
         assert torch.equal(again.cpu(), want)
-        print(f"[fallback] starved generation of {n} tokens took {1e3 * (t1 - t0):.0f} ms on 32 CUs, incl. one 20 ms bounded sweep and the re-run")
+        print(f"[fallback] starved generation of {n} tokens took {1e3 * dt:.0f} ms on 32 CUs, incl. one 20 ms bounded sweep and the re-run")
     finally:
-        side.synchronize()
         eng.set_option("chain_resident", 1)                          # re-arm for the tests that follow
     assert eng.get_option("chain_resident") == 1
     back, _ = eng.generate(eng.prefix, max_new_tokens=n, suppress_eos=True)

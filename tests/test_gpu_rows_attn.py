@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from meshanything_amd.config import MAConfig, DTYPE_BF16, DTYPE_F16
-from conftest import load_weights_cached, mouse_variants
+from conftest import generate_on_a_starved_device, load_weights_cached, mouse_variants
 
 pytestmark = pytest.mark.gpu
 
@@ -146,22 +146,12 @@ def test_fused_first_half_falls_back_when_the_device_is_shared(eng8):
     eng8.set_option("chain_resident", 1)
     want = want.cpu()
     base = eng8.get_option("chain_fallbacks")
-    side = torch.cuda.Stream()
-    release = torch.zeros(1, dtype=torch.int32).pin_memory()
-    torch.cuda.synchronize()
-    eng8.occupy_cus(224, 2_000_000, stream=side, release=release)
-    try:
-        with pytest.warns(RuntimeWarning, match="fused decode launches timed out"):
-            got, got_len = eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True)
-    finally:
-        release[0] = 1
-    torch.cuda.synchronize()
+    (got, got_len), _, _ = generate_on_a_starved_device(eng8, lambda: eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True))
     try:
         assert eng8.get_option("chain_fallbacks") == base + 1, "the starved grid was not noticed"
         assert eng8.get_option("chain_resident") == 0
         assert torch.equal(got.cpu(), want) and list(got_len) == list(want_len)
     finally:
-        side.synchronize()
         eng8.set_option("chain_resident", 1)
     back, _ = eng8.generate(eng8.prefix, max_new_tokens=n, suppress_eos=True)
     assert back.shape == (8, n)
