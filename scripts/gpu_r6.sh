@@ -56,7 +56,7 @@ for st in $STAGES; do
       done
       python $R/scripts/pmc_summary.py $O/r06_pmc_decode_raw.json /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $O/pmc_decode_summary.log 2>&1
       rm -rf /tmp/pmc_mfma
-      timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- python $R/scripts/prof_dense.py --batches 64 --iters 1 > $O/pmc_mfma.log 2>&1
+      timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d /tmp/pmc_mfma -o p --output-format csv -- python $R/scripts/prof_dense.py --batches 64 --iters 1 --options prefill_tail=0 > $O/pmc_mfma.log 2>&1      # (one-stream prefill: counter collection runs kernels one at a time; the tail chain's 10 small launches per layer would only add their collection overhead to the denominator)
       python $R/scripts/pmc_summary.py $O/r06_pmc_dense_mfma_raw.json /tmp/pmc_mfma > $O/pmc_mfma_summary.log 2>&1
       python $R/scripts/pmc_r2_report.py $O/r06_pmc_decode_raw.json $O/r06_pmc_dense_mfma_raw.json $O r06
       head -c 600 $O/r06_pmc_decode_traffic.json; echo; python - <<PY
