@@ -667,7 +667,7 @@ def test_prefill_kv_written_by_the_qkv_gemm_equals_the_copy(golden_dir, policy):
     eng.close()
 
 
-@pytest.mark.parametrize("policy,B", [("bf16", 64), ("fp16", 64), ("bf16", 16), ("bf16", 24), ("bf16", 8), ("fp16", 40)])
+@pytest.mark.parametrize("policy,B", [("bf16", 64), ("fp16", 64), ("bf16", 16), ("bf16", 24), ("bf16", 8), ("fp16", 40), ("bf16", 72)])      # (72: two row groups, 64 + 8, the second at row 64 of the cache)
 def test_prefill_last_rows_as_their_own_chain_equal_the_one_stream_form(golden_dir, policy, B):
     """Round 6: M = B x 257 leaves B rows behind the 256-row tiles -- the last B positions of the last sample, which no other row ever reads (causal
     attention).  With option prefill_tail (default 2: on a stream of the lowest priority; 1: default priority) they run all 24 layers as a chain of their own on a second stream, fed per layer with the main
