@@ -166,7 +166,7 @@ struct ma_engine {
     hipStream_t tail_stream_low = nullptr;      // (prefill_tail = 2)
     hipStream_t tail_stream = nullptr; hipEvent_t tail_fork = nullptr, tail_join = nullptr; std::vector<hipEvent_t> tail_kv;      // its stream; per layer: "the main rows' K / V are in the planes"
     void* a_patt_tail = nullptr; bf16_t* a_vt_tail = nullptr; size_t vt_tail_elems = 0;      // its attention output (64 rows) and V^T workspace (one sample)
-    int opt_gemm_splitk = 1;         // prefill fc2 of small batches as 4 partial sums along K, added up by the LayerNorm that follows (0: never; A/B)
+    int opt_gemm_splitk = 2;         // prefill fc2 (1) and out_proj (2, default) of small batches as 4 | 2 partial sums along K, added up by the LayerNorm that follows (0: never; A/B)
     void *a_feat = nullptr, *a_dataln = nullptr, *a_kv = nullptr, *a_q = nullptr, *a_ln = nullptr, *a_qkv = nullptr, *a_att = nullptr, *a_mlp = nullptr,
          *a_cat = nullptr, *a_mean = nullptr, *a_fein = nullptr, *a_x = nullptr, *a_ph = nullptr, *a_pqkv = nullptr, *a_patt = nullptr, *a_pffn = nullptr;
     unsigned char* w_mask = nullptr;
@@ -324,7 +324,8 @@ void gemm_res_ln(ma_engine* e, hipStream_t s, const void* A, int lda, const std:
                  float* y, int M, int H, bool allow_split, int part = 0) {
     const bool fuse = part == 0 && e->opt_fuse_ln && e->dense16 && e->chain_resident && e->d_ln_gran && (size_t)(M / 256) * (size_t)(H / 256) <= e->ln_gran_tiles;
     GemmSplitK sk;
-    sk.max_parts = (allow_split && e->opt_gemm_splitk && e->dense16 && H == 1024 && (long)M * H <= e->p_y_part_stride) ? 4 : 1;
+    // (from 8 samples on, like the tail chain: below that a sample's prefill keeps the bits of its batch-1 run -- the GEMMs run on row-independent tiles only)
+    sk.max_parts = (allow_split && e->opt_gemm_splitk && e->dense16 && H == 1024 && M >= 2048 && (long)M * H <= e->p_y_part_stride) ? 4 : 1;
     sk.part_stride = e->p_y_part_stride;
     if (fuse) {
         GemmLnFuse lf;

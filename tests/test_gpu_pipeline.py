@@ -703,8 +703,9 @@ def test_prefill_last_rows_as_their_own_chain_equal_the_one_stream_form(golden_d
 
 @pytest.mark.parametrize("policy", ["bf16", "fp16"])
 def test_prefill_of_16_samples_with_fc2_split_along_k(golden_dir, policy):
-    """Round 6: at 16 samples (M = 4 112) the prefill's fc2 -- N = 1024: 64 tiles of 256 x 256, each 64 K-tiles deep -- runs as FOUR partial sums along
-    K (csrc/gemm256.hpp, GemmSplitK) that the LayerNorm behind it adds up (ln_rows2_kernel, KS form); q|k|v takes the persistent tiles at 0.75 round.
+    """Round 6: at 16 samples (M = 4 112) the prefill's fc2 -- N = 1024: 64 tiles of 256 x 256, each 64 K-tiles deep -- and its out_proj (16 K-tiles) run as
+    FOUR partial sums along K (csrc/gemm256.hpp, GemmSplitK; option gemm_splitk, default 2 = both) that the LayerNorm behind each adds up (ln_rows2_kernel,
+    KS form); q|k|v takes the persistent tiles at 0.75 round.
     The summation order along K differs from the unsplit kernel's, so the two are compared the way every 16-bit path is: each against the oracle along
     its own greedy stream, and against each other on the logits of the same forced stream."""
     from meshanything_amd.engine import Engine
@@ -719,7 +720,7 @@ def test_prefill_of_16_samples_with_fc2_split_along_k(golden_dir, policy):
     load_weights_cached(eng, cfg, init=FULL_INIT)
     x = mouse_variants(golden_dir, B)
     prefix = env.oracle.process_point_feature(env.oracle.encode_latents(x))
-    assert eng.get_option("gemm_splitk") == 1
+    assert eng.get_option("gemm_splitk") == 2
     try:
         toks, lengths, lg = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, return_logits=True)
         v = _check_greedy(env, prefix, toks, lengths, suppress_eos=True)
@@ -728,10 +729,10 @@ def test_prefill_of_16_samples_with_fc2_split_along_k(golden_dir, policy):
         t0, _, lg0 = eng.generate(prefix.cuda(), max_new_tokens=n, suppress_eos=True, forced_tokens=toks, return_logits=True)
         err = float((lg - lg0).abs().max())
         same = float((t0 == toks).float().mean())
-        print(f"[{policy}] 16-sample prefill, fc2 as 4 partial sums along K vs unsplit: max abs logit difference over {n} steps x {B} rows {err:.5f}, same picks {same * 100:.1f} %")
+        print(f"[{policy}] 16-sample prefill, out_proj and fc2 as 4 partial sums along K vs unsplit: max abs logit difference over {n} steps x {B} rows {err:.5f}, same picks {same * 100:.1f} %")
         assert err <= {"bf16": 3e-2, "fp16": 4e-3}[policy] and same >= 0.9
     finally:
-        eng.set_option("gemm_splitk", 1)
+        eng.set_option("gemm_splitk", 2)
     eng.close()
 
 
