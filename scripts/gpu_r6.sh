@@ -4,6 +4,10 @@
 #   calib   scripts/calib_library_gemm.py    bench   bench.py (defaults)         b8 / cfg5   bench.py --batch 8 [--faces 1600]
 #   exp     the MA_EXPERIMENTAL tests        trace8  the 8-row step's timeline
 #   gemmtests  the dense GEMM kernel tests (-s: their timing lines)    stress  scripts/stress_gemm256.py
+#   fp32    the fp32 policy on the fused launches (bitwise tests, gates, one mesh each way)      cfg3    bench.py --batch 64 --sampling
+#   soak    the 8-row two-launch layer in round 5's failing form      pmc     HBM bytes of the decode launches + matrix-core busy of the dense phases (separate passes)
+#   phase   kernel trace of ONE dense phase      benchprof   rocprofv3 --kernel-trace --stats of bench.py and of bench.py --batch 8
+# other one-off measurements of the round: scripts/time_fp32_policy.py, provoke_queue_eviction.py, soak_fused_engine_churn.py, analyze_tail_chain.py (see profiles/README.md)
 TAG=${TAG:-r6}; STAGES=${STAGES:-suite}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
