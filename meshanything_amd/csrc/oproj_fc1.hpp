@@ -246,26 +246,25 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
     } else {
         // ---- (5) all-gather of relu(fc1).  fc2 consumes it rounded to bf16, so a granule carries TWO values (bf16 pair + epoch): 2 granules
         //      per wave out, 2048 in all, wave w sweeps granules [512 w, 512 w + 512) -- half the polling of one value per granule ------------
-        //      fp32 policy: the value is consumed unrounded, one fp32 per granule (4096 granules, 1024 per wave in two passes of eight loads)
+        //      fp32 policy: the value is consumed unrounded, one fp32 per granule (4096 granules, 1024 per wave in one pass of sixteen loads per lane)
         u64* g2 = a.gran2 + (size_t)brow * KF;
         if constexpr (sizeof(ST) == 4) {
             if (lane < 4) ps_publish(g2, 16 * b + 4 * w + lane, epoch, __float_as_uint(outv));
             after_ffn_publish();
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                const gu64* g64 = (const gu64*)g2 + w * 1024 + half * 512;
-                float* fr = ffl + w * 1024 + half * 512;
+            {   // (ONE pass of sixteen loads per lane: two passes of eight cost a second round trip, +0.5 us per launch)
+                const gu64* g64 = (const gu64*)g2 + w * 1024;
+                float* fr = ffl + w * 1024;
                 u64 t0 = __builtin_amdgcn_s_memrealtime();
-                unsigned spins = 0, pend = 0xffu;
+                unsigned spins = 0, pend = 0xffffu;
                 for (;;) {
-                    u64 v[8];
+                    u64 v[16];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < 16; ++k) {
                         v[k] = (u64)epoch << 32;
                         if ((pend >> k) & 1u) v[k] = __hip_atomic_load(g64 + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
+                    for (int k = 0; k < 16; ++k) {
                         if ((pend >> k) & 1u) {
                             const bool ok = (unsigned)(v[k] >> 32) == epoch;
                             if (ok) fr[k * 64 + lane] = __uint_as_float((unsigned)v[k]);
@@ -277,7 +276,7 @@ __device__ __forceinline__ void oproj_fc1_body(OprojFc1Args a, const int b, cons
                     if (xchg_expired(spins, t0, a.err)) {
                         if (lane == 0) xchg_raise(a.err, OF_ERR_GATHER, spins);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) fr[k * 64 + lane] = 0.f;
+                        for (int k = 0; k < 16; ++k) fr[k * 64 + lane] = 0.f;
                         break;
                     }
                 }
