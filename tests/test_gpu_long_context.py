@@ -80,7 +80,7 @@ def _against_anchor(lg, a, first, n, policy, what):
             "decisive": int(decisive.sum()), "err_by_third": thirds, "n": n - first}
 
 
-@pytest.mark.parametrize("faces,policy", [(800, "bf16"), (800, "fp16"), (800, "fp32"), (1600, "bf16"), (1600, "fp32")])
+@pytest.mark.parametrize("faces,policy", [(800, "bf16"), (800, "fp16"), (800, "fp32"), (1600, "bf16"), (1600, "fp16"), (1600, "fp32")])
 def test_full_length_along_the_reference_path(policy, faces, anchor, golden_dir):
     """BASELINE configs[1] (800 faces: 7 202 tokens, the benchmarked workload) and configs[4]'s shape at batch 1 (1 600 faces: 14 402 tokens),
     every step against the reference's own decode."""
