@@ -130,7 +130,11 @@ MA_API void ma_engine_destroy(ma_engine *e);
 /* integer options (debug / A-B switches); see DESIGN.md.  Unknown names -> MA_ERR_INVALID. */
 MA_API int  ma_engine_set_option(ma_engine *e, const char *name, int64_t value);
 /* reads an option back as the engine will apply it (e.g. "fuse_qkv_attn" is 1 only if the option is on AND the configuration is
- * eligible); names: fuse_qkv_attn, fuse_oproj_fc1, decode_impl, persist_available, use_graph, dense_rows, mfma_min_batch */
+ * eligible); names: fuse_qkv_attn, fuse_oproj_fc1, decode_impl, persist_available, use_graph, dense_rows, mfma_min_batch, ...
+ * (INTEGRATION.md section 3 lists them all, with the read-only health counters of the fused launches).
+ * Streams: every entry point enqueues on the caller's stream and is ordered with it.  ma_generate's prefill of >= 8 samples (16-bit
+ * policies) additionally runs the last rows of its GEMMs on a second, engine-owned stream of the lowest priority, forked from and
+ * joined to the caller's stream inside the call (option "prefill_tail" = 0 keeps everything on the caller's stream). */
 MA_API int  ma_engine_get_option(ma_engine *e, const char *name, int64_t *value);
 
 /* ---- weights ------------------------------------------------------------------------------------------ */
