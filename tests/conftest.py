@@ -222,7 +222,6 @@ def mouse_variants(golden_dir, k):
         out.append(normalize_pc(pc) if i else np.load(os.path.join(golden_dir, "dataset.npz"))["mouse_norm"])
     return torch.from_numpy(np.stack(out))
 
-import contextlib
 import gc
 
 _HEALTH = ("chain_fallbacks", "xchg_timeouts", "scalar_sweep_rescues")
@@ -312,14 +311,3 @@ def _collect_before_gpu_tests(request):
     if request.node.get_closest_marker("gpu") is not None:
         gc.collect()
     yield
-
-
-@contextlib.contextmanager
-def fused_path_must_hold(eng, what=""):
-    """The strict form of fused_generate for a block of several generations: the counters must not move across the block (no second try)."""
-    armed = eng.get_option("chain_resident") == 1
-    before = {k: eng.get_option(k) for k in _HEALTH}
-    yield
-    if armed:
-        after = {k: eng.get_option(k) for k in _HEALTH}
-        assert after == before and eng.get_option("chain_resident") == 1, _health_note(eng, what, before, after) + ": what was verified is the fall-back chain"
