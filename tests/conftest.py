@@ -307,7 +307,9 @@ def generate_on_a_starved_device(eng, gen, cus=224, attempts=5):
 def _collect_before_gpu_tests(request):
     """Engines (and torch tensors) that are only reachable through reference cycles are destroyed when the collector gets round to it: ma_engine_destroy
     is a string of hipFree calls -- device-wide synchronisations -- and one landing in the middle of a test that holds most of the device with a
-    second stream (the *falls_back* tests) stalls the launches under test until that stream lets go (seen once, round 6).  Collect between tests."""
+    second stream (the *falls_back* tests) stalls the launches under test until that stream lets go.  (One of the two explanations considered for a stalled
+    fall-back test in round 6; the other -- an engine stream sharing the hog's hardware queue -- was the one confirmed, generate_on_a_starved_device.  Collecting
+    between tests costs nothing and keeps engine destruction out of the tests' timed regions.)"""
     if request.node.get_closest_marker("gpu") is not None:
         gc.collect()
     yield
